@@ -1,0 +1,83 @@
+"""ctypes binding of libendosurf_hip.so (C ABI declared in include/endosurf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing/using the renderer raises.  Build it with ``python -m endosurf_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libendosurf_hip.so")
+
+_c_float_p = C.c_void_p   # device pointers travel as integers (torch .data_ptr())
+
+
+class es_points(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("t", C.c_void_p), ("dirs", C.c_void_p), ("rays", C.c_void_p), ("z", C.c_void_p),
+                ("mode", C.c_int), ("t_scalar", C.c_int), ("n_per_ray", C.c_int), ("ldz", C.c_int), ("M", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/endosurf_hip.h must be listed here
+# (tests/test_abi.py cross-checks the header against this table and against the built .so).
+PROTOTYPES = {
+    "es_abi_version": (C.c_int, []),
+    "es_last_error": (C.c_char_p, []),
+    "es_init": (C.c_int, []),
+    "es_param_floats": (C.c_int64, []),
+    "es_param_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "es_param_variance_off": (C.c_int64, []),
+    "es_weff_floats": (C.c_int64, []),
+    "es_weff_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "es_packed_floats": (C.c_int64, []),
+    "es_weightnorm_pack": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+    "es_weightnorm_backward": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+    "es_query_sdf": (C.c_int, [C.POINTER(es_points), _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class EndoSurfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built — there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EndoSurfHipError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m endosurf_amd.build). "
+            "endosurf_amd has no CPU/PyTorch fallback for the renderer hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.es_abi_version() != 1:
+        raise EndoSurfHipError("libendosurf_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().es_last_error()
+        raise EndoSurfHipError(f"{what or 'libendosurf_hip'} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI takes contiguous buffers"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,239 @@
+// Building blocks of the fused MLP "chain" kernels (gfx950 / CDNA4, wave64).
+//
+// Execution model of every chain kernel:
+//   * one workgroup = 256 threads = 4 wavefronts (one per SIMD) owns a tile of TM = 64 rows;
+//   * the activation tile lives in LDS, k-major ([k][row], XOR-swizzled) so that the MFMA A operand
+//     (lane l -> row l&31, k-step l>>5) is a conflict-free ds_read_b32 and the epilogue writes 4
+//     consecutive rows of one column as one conflict-free ds_write_b128;
+//   * weights are pre-packed (pack.hip) into MFMA B-fragment order and streamed global->VGPR by the
+//     wave that owns the output columns (each weight element is read once per workgroup, from L2),
+//     software-prefetched two groups of 4 k-steps ahead; they never round-trip through LDS;
+//   * the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, the fp32 matrix peak of gfx950);
+//     each wave accumulates 64 rows x 64 columns in 4 accumulators of 16 VGPRs;
+//   * the layer output is produced in-register, fused with bias/activation/tangent masking, written
+//     back in place to the LDS tile (2 barriers per layer) and optionally streamed to HBM for backward.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "arch.h"
+
+namespace es {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 64;                     // rows per workgroup tile
+constexpr int NTHREADS = 256;              // 4 wavefronts
+constexpr int MAIN_FLOATS = HID * TM;      // 64 KiB main activation tile
+constexpr int AUX_K = 128;
+constexpr int AUX_FLOATS = AUX_K * TM;     // 32 KiB auxiliary tile (encodings / small skip inputs / small adjoints)
+constexpr int SCR_FLOATS = 2048;           // 8 KiB scratch
+constexpr int LDS_FLOATS = MAIN_FLOATS + AUX_FLOATS + SCR_FLOATS;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;  // 106 496 B of the 160 KiB per CU
+
+// element (k, row) of a k-major tile
+__device__ __forceinline__ int swz(int k, int r) { return k * TM + (r ^ ((k & 15) << 2)); }
+
+template <int RTC, int NTC>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[RTC][NTC]) {
+#pragma unroll
+    for (int i = 0; i < RTC; ++i)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+// acc[ri][ni] += A[rows of row-tile rt0+ri][0 .. 8*KG) * B[0 .. 8*KG)[cols of n-tile nt0+ni]
+// A = LDS tile ``At`` (k-major, swizzled); B = packed segment ``W`` ([nt][g][lane] float4, KG groups).
+template <int KG, int RTC, int NTC>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[RTC][NTC], const float* At, const float4* __restrict__ W,
+                                         int rt0, int nt0, int lane) {
+    constexpr int PF = 4;
+    constexpr bool GUARD = (KG % (2 * PF)) != 0;
+    const int lo = lane & 31, hi = lane >> 5;
+    float4 b0[PF][NTC], b1[PF][NTC];
+    const float4* wl = W + lane;
+
+    auto loadB = [&](float4(&b)[PF][NTC], int g0) {
+#pragma unroll
+        for (int gi = 0; gi < PF; ++gi)
+#pragma unroll
+            for (int ni = 0; ni < NTC; ++ni)
+                if (!GUARD || g0 + gi < KG) b[gi][ni] = wl[(size_t)((nt0 + ni) * KG + g0 + gi) * 64];
+    };
+    auto comp = [&](const float4(&b)[PF][NTC], int g0) {
+#pragma unroll
+        for (int gi = 0; gi < PF; ++gi) {
+            if (!GUARD || g0 + gi < KG) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 8 * (g0 + gi) + 2 * j + hi;
+                    float a[RTC];
+#pragma unroll
+                    for (int ri = 0; ri < RTC; ++ri) a[ri] = At[swz(k, (rt0 + ri) * 32 + lo)];
+#pragma unroll
+                    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+                        for (int ni = 0; ni < NTC; ++ni)
+                            acc[ri][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], f4c(b[gi][ni], j), acc[ri][ni], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    loadB(b0, 0);
+    if constexpr (KG > 2 * PF) {
+#pragma unroll 1
+        for (int g0 = 0; g0 < KG; g0 += 2 * PF) {
+            if (!GUARD || g0 + PF < KG) loadB(b1, g0 + PF);
+            comp(b0, g0);
+            if (g0 + 2 * PF < KG) loadB(b0, g0 + 2 * PF);
+            if (!GUARD || g0 + PF < KG) comp(b1, g0 + PF);
+        }
+    } else {
+        if (PF < KG) loadB(b1, PF);
+        comp(b0, 0);
+        if (PF < KG) comp(b1, PF);
+    }
+}
+
+// Visit the accumulator as quads: f(row, col, v[4]) where v holds rows row..row+3 of column col
+// (C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+template <int RTC, int NTC, class F>
+__device__ __forceinline__ void for_quads(f32x16 (&acc)[RTC][NTC], int rt0, int nt0, int lane, F&& f) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[ri][ni][4 * q + 0], acc[ri][ni][4 * q + 1], acc[ri][ni][4 * q + 2], acc[ri][ni][4 * q + 3]};
+                f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v);
+            }
+}
+
+// Same visiting order without an accumulator (element-wise stages that run "in epilogue layout").
+template <int RTC, int NTC, class F>
+__device__ __forceinline__ void for_quads_noacc(int rt0, int nt0, int lane, F&& f) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo);
+}
+
+__device__ __forceinline__ void lds_store_quad(float* At, int col, int row, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(&At[swz(col, row)]) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_load_quad(const float* At, int col, int row, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(&At[swz(col, row)]);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void lds_add_quad(float* At, int col, int row, const float (&v)[4]) {
+    float4* p = reinterpret_cast<float4*>(&At[swz(col, row)]);
+    float4 t = *p;
+    t.x += v[0]; t.y += v[1]; t.z += v[2]; t.w += v[3];
+    *p = t;
+}
+// rows row..row+3 of column col of a row-major [rows][ld] HBM buffer (each wave store = 2 x 128 B lines)
+__device__ __forceinline__ void g_store_quad(float* __restrict__ base, size_t grow0, int ld, int row, int col, const float (&v)[4]) {
+    float* p = base + (grow0 + row) * (size_t)ld + col;
+    p[0] = v[0]; p[ld] = v[1]; p[2 * ld] = v[2]; p[3 * ld] = v[3];
+}
+__device__ __forceinline__ void g_load_quad(const float* __restrict__ base, size_t grow0, int ld, int row, int col, float (&v)[4]) {
+    const float* p = base + (grow0 + row) * (size_t)ld + col;
+    v[0] = p[0]; v[1] = p[ld]; v[2] = p[2 * ld]; v[3] = p[3 * ld];
+}
+
+// Load a [64][256] row-major HBM tile into the k-major LDS tile (rows grow0.. of ``src`` with leading dim ld).
+__device__ __forceinline__ void load_tile_256(float* At, const float* __restrict__ src, size_t grow0, int ld, int tid) {
+    const int r = tid >> 2, c4 = tid & 3;          // 4 threads per row, 16 float4 each
+    const float* p = src + (grow0 + r) * (size_t)ld;
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+        const int c = 4 * (c4 + 4 * jj);
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        At[swz(c + 0, r)] = v.x; At[swz(c + 1, r)] = v.y; At[swz(c + 2, r)] = v.z; At[swz(c + 3, r)] = v.w;
+    }
+}
+
+// ---- activations ---------------------------------------------------------------------------------
+// nn.Softplus(beta=100, threshold=20)  (reference endosurf.py:771):  z if 100z > 20 else log1p(exp(100z))/100.
+// Evaluated branch-free as max(z,0) + log(1 + exp(-|100z|))/100 on the hardware exp/log units: identical above
+// the threshold to fp32 rounding, absolute error <= ~1e-9 below it (the accurate libm chain costs ~130 VALU
+// instructions per element, which would rival the MFMA time of a 256x256 layer).
+__device__ __forceinline__ float softplus100(float z) {
+    return fmaxf(z, 0.f) + 0.01f * __logf(1.f + __expf(-fabsf(100.f * z)));
+}
+// softplus'(z) = sigmoid(100 z) recovered from s = softplus(z):  1 - exp(-100 s)   (series where that cancels)
+__device__ __forceinline__ float softplus100_grad_from_s(float s) {
+    const float x = 100.f * s;
+    return x < 0.02f ? x * (1.f - x * (0.5f - x * (1.f / 6.f))) : 1.f - __expf(-x);
+}
+
+// ---- frequency encoding (reference src/renderer/encoder.py:40-54) ----------------------------------
+// element ``idx`` of [x, sin(2^0 x), cos(2^0 x), ...] for a D-dim input with value x_c of its coordinate:
+// layout index = D + (2*i + fn)*D + c  for frequency i, fn (0 sin / 1 cos), coordinate c.
+__device__ __forceinline__ int enc_index(int D, int i, int fn, int c) { return D + (2 * i + fn) * D + c; }
+
+// out[NOUT][row] = sum_k Wrows[i][k] * At[k][row] (+ bias handled by caller): VALU path for tiny-N layers.
+// Partial sums of the 4 waves go to scr[(part*NOUT + i)*64 + row]; caller barriers and reduces.
+template <int NOUT>
+__device__ __forceinline__ void smalln_partial(const float* At, const float* __restrict__ Wrows, int ldw, float* scr, int tid) {
+    const int row = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float s[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) s[i] = 0.f;
+    const int k0 = part * 64;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) {
+        const float a = At[swz(k0 + kk, row)];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) s[i] = fmaf(Wrows[i * ldw + k0 + kk], a, s[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) scr[(part * NOUT + i) * 64 + row] = s[i];
+}
+template <int NOUT>
+__device__ __forceinline__ float smalln_reduce(const float* scr, int i, int row) {
+    return (scr[(0 * NOUT + i) * 64 + row] + scr[(1 * NOUT + i) * 64 + row]) + (scr[(2 * NOUT + i) * 64 + row] + scr[(3 * NOUT + i) * 64 + row]);
+}
+
+// ---- point source: where a kernel gets its query points from -----------------------------------------
+// mode 0: explicit x[M][3], t[M] (or t[0] if t_scalar);  optional dirs[M][3]
+// mode 1: ray samples: point i -> ray i / n, sample i % n:  x = o + d/(d.z+1e-6) * z[ray*ldz + s], t = rays[ray][8],
+//         dir = rays[ray][3:6]   (reference endosurf.py:66, 87, 153)
+struct PointSrc {
+    const float* x;
+    const float* t;
+    const float* dirs;
+    const float* rays;
+    const float* z;
+    int mode, t_scalar, n_per_ray, ldz;
+    int M;
+};
+__device__ __forceinline__ void load_point(const PointSrc& s, int i, float (&x)[3], float& t, float (&d)[3]) {
+    if (i >= s.M) { x[0] = x[1] = x[2] = 0.f; t = 0.f; d[0] = d[1] = 0.f; d[2] = 1.f; return; }
+    if (s.mode == 0) {
+        x[0] = s.x[3 * (size_t)i]; x[1] = s.x[3 * (size_t)i + 1]; x[2] = s.x[3 * (size_t)i + 2];
+        t = s.t[s.t_scalar ? 0 : i];
+        if (s.dirs) { d[0] = s.dirs[3 * (size_t)i]; d[1] = s.dirs[3 * (size_t)i + 1]; d[2] = s.dirs[3 * (size_t)i + 2]; }
+        else { d[0] = d[1] = 0.f; d[2] = 1.f; }
+    } else {
+        const int ray = i / s.n_per_ray, smp = i - ray * s.n_per_ray;
+        const float* r = s.rays + 9 * (size_t)ray;
+        const float zz = s.z[(size_t)ray * s.ldz + smp];
+        const float inv = r[5] + 1e-6f;
+        d[0] = r[3]; d[1] = r[4]; d[2] = r[5];
+        x[0] = r[0] + (r[3] / inv) * zz; x[1] = r[1] + (r[4] / inv) * zz; x[2] = r[2] + (r[5] / inv) * zz;
+        t = r[8];
+    }
+}
+
+}  // namespace es

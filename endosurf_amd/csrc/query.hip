@@ -1,0 +1,137 @@
+// K2: fused no-grad SDF query  sdf(x + deform(x, t))  — the reference's
+// EndoSurfNet.get_sdf_from_observed_space (endosurf.py:570-579: DeformNetwork.forward :724-738 then
+// SDFNetwork.sdf :788-791), used by hierarchical up-sampling (:92, :281), ray marching (:375), the secant
+// refinement (:435) and mesh extraction (:493).  One launch runs both 9-layer MLPs per 64-point tile with the
+// activations resident in LDS; only 16 B/point are read and 4 B/point written.
+#include "chain_common.h"
+#include "encode.h"
+#include "launch.h"
+#include "tabs.h"
+
+namespace es {
+
+template <bool DEFORM>
+__global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, const float4* __restrict__ packed,
+                                                        const float* __restrict__ weff, float* __restrict__ sdf_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* px = scr;          // [3][64]
+    float* pt = scr + 192;    // [64]
+    float* red = scr + 256;   // [4][<=3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TM;
+
+    if (tid < 64) {
+        float x[3], t, d[3];
+        load_point(src, row0 + tid, x, t, d);
+        px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2]; pt[tid] = t;
+    }
+    __syncthreads();
+
+    if (DEFORM) {
+        // ---- deformation MLP, value only: x_c = x + MLP([enc6(x), enc6(t)]) ----
+        encode3<6>(aux, 0, px, tid);
+        encode1<6>(aux, 39, pt, tid);
+        zero_rows(aux, 52, 56, tid);
+        __syncthreads();
+        {
+            f32x16 acc[2][2];
+            acc_zero(acc);
+            gemm_seg<7, 2, 2>(acc, aux, packed + tb.segoff[DF0], 0, 2 * wave, lane);
+            const float* bias = weff + tb.boff[NET_D * LAYERS + 0];
+            for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+                const float b = bias[col];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+                lds_store_quad(mainT, col, row, v);
+            });
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            f32x16 acc[2][2];
+            acc_zero(acc);
+            gemm_seg<32, 2, 2>(acc, mainT, packed + tb.segoff[DF0 + l], 0, 2 * wave, lane);
+            __syncthreads();
+            const float* bias = weff + tb.boff[NET_D * LAYERS + l];
+            for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+                if (l == 3 && col >= 204) {
+                    lds_load_quad(aux, col - 204, row, v);   // IDR skip: next input = [h(204) | enc(52)] (1/sqrt2 folded into W4)
+                } else {
+                    const float b = bias[col];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+                }
+                lds_store_quad(mainT, col, row, v);
+            });
+            __syncthreads();
+        }
+        smalln_partial<3>(mainT, weff + tb.woff[NET_D * LAYERS + 8], 256, red, tid);
+        __syncthreads();
+        if (tid < 192) {
+            const int i = tid >> 6, row = tid & 63;
+            px[i * 64 + row] += smalln_reduce<3>(red, i, row) + weff[tb.boff[NET_D * LAYERS + 8] + i];
+        }
+        __syncthreads();
+    }
+
+    // ---- SDF MLP on x_c, output column 0 only ----
+    encode3<6>(aux, 0, px, tid);
+    zero_rows(aux, 39, 40, tid);
+    __syncthreads();
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<5, 2, 2>(acc, aux, packed + tb.segoff[SF0], 0, 2 * wave, lane);
+        const float* bias = weff + tb.boff[NET_S * LAYERS + 0];
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
+            lds_store_quad(mainT, col, row, v);
+        });
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
+        gemm_seg<32, 2, 2>(acc, mainT, packed + tb.segoff[seg], 0, 2 * wave, lane);
+        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, packed + tb.segoff[SF4A], 0, 2 * wave, lane);   // NeRF skip: + enc part
+        __syncthreads();
+        const float* bias = weff + tb.boff[NET_S * LAYERS + l];
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
+            lds_store_quad(mainT, col, row, v);
+        });
+        __syncthreads();
+    }
+    smalln_partial<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 64 && row0 + tid < src.M) sdf_out[row0 + tid] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+}
+
+int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (int e = allow_big_lds(k_query_sdf<true>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<false>, LDS_BYTES)) return e;
+        attr_done = true;
+    }
+    if (src.M <= 0) return ST_OK;
+    const Tabs tb = make_tabs();
+    const dim3 grid((src.M + TM - 1) / TM), block(NTHREADS);
+    if (use_deform)
+        hipLaunchKernelGGL(k_query_sdf<true>, grid, block, LDS_BYTES, st, src, tb, reinterpret_cast<const float4*>(packed), weff, sdf_out);
+    else
+        hipLaunchKernelGGL(k_query_sdf<false>, grid, block, LDS_BYTES, st, src, tb, reinterpret_cast<const float4*>(packed), weff, sdf_out);
+    return hip_last("query_sdf");
+}
+
+}  // namespace es
