@@ -19,6 +19,19 @@ class es_points(C.Structure):
                 ("mode", C.c_int), ("t_scalar", C.c_int), ("n_per_ray", C.c_int), ("ldz", C.c_int), ("M", C.c_int)]
 
 
+class es_composite_args(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("rays", "z")] + [("ldz", C.c_int)]
+                + [(n, C.c_void_p) for n in ("sdf", "g_o", "rgb", "variance")]
+                + [("N", C.c_int), ("S", C.c_int), ("sample_dist", C.c_float), ("cos_anneal", C.c_float)]
+                + [(n, C.c_void_p) for n in ("color", "depth", "weights", "cdf", "weight_max", "eik_acc", "wmax_idx",
+                                             "g_color", "g_depth", "g_weights", "g_cdf", "g_wmax", "g_gradients_o", "g_eik",
+                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc")])
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
 # name -> (restype, argtypes); every symbol declared in include/endosurf_hip.h must be listed here
 # (tests/test_abi.py cross-checks the header against this table and against the built .so).
 PROTOTYPES = {
@@ -35,6 +48,16 @@ PROTOTYPES = {
     "es_weightnorm_pack": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_weightnorm_backward": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_query_sdf": (C.c_int, [C.POINTER(es_points), _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+    "es_ray_setup": (_I, [_P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P]),
+    "es_upsample_step": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
+    "es_merge_sdf": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "es_mid_z": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "es_composite_forward": (_I, [C.POINTER(es_composite_args), _P]),
+    "es_composite_backward": (_I, [C.POINTER(es_composite_args), _P]),
+    "es_march_find": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "es_secant_points": (_I, [_P, _P, _I, _P, _P, _P]),
+    "es_secant_update": (_I, [_P, _I, _F, _P, _P, _P]),
+    "es_march_finish": (_I, [_P, _P, _I, _P, _P]),
 }
 
 _lib = None

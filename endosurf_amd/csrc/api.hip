@@ -4,11 +4,26 @@
 #include "arch.h"
 #include "chain_common.h"
 #include "launch.h"
+#include "ray_args.h"
 
 namespace es {
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st);
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
+
+int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
+              float* far_out, hipStream_t st);
+int upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
+                  float inv_s, float* z_new, float* z_out, int ld_out, int* src_idx, hipStream_t st);
+int merge_sdf(const float* sdf_in, int ld_in, const float* sdf_new, int n_imp, const int* src_idx, int ld_out, int N, int n,
+              float* sdf_out, hipStream_t st);
+int mid_z(const float* z, int ldz, int N, int S, float sample_dist, float* mid, hipStream_t st);
+int composite(const CompositeArgs& a, int backward, hipStream_t st);
+int march_find(const float* sdf, const float* dprop, int N, int n, float tau, float* state, int* flags, float* d_pred, hipStream_t st);
+int secant_points(const float* rays, const float* d_pred, int N, float* x, float* t, hipStream_t st);
+int secant_update(const float* sdf_mid, int N, float tau, float* state, float* d_pred, hipStream_t st);
+int march_finish(const float* d_pred, const int* flags, int N, float* d_out, hipStream_t st);
+static_assert(sizeof(es_composite_args) == sizeof(CompositeArgs), "es_composite_args must mirror es::CompositeArgs");
 
 static_assert(sizeof(es_points) == sizeof(PointSrc), "es_points must mirror es::PointSrc");
 static inline PointSrc to_src(const es_points* p) {
@@ -88,6 +103,55 @@ int es_query_sdf(const es_points* pts, const float* packed, const float* weff, f
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
     return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream);
+}
+
+
+int es_ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz,
+                 float* near_out, float* far_out, void* stream) {
+    ES_REQUIRE(rays && z && N >= 0 && n >= 1 && ldz >= n, "es_ray_setup arguments");
+    return ray_setup(rays, u, N, n, sample_dist, lin_mode, z, ldz, near_out, far_out, (hipStream_t)stream);
+}
+int es_upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
+                     float inv_s, float* z_new, float* z_out, int ld_out, int32_t* src_idx, void* stream) {
+    ES_REQUIRE(rays && z_in && sdf_in && z_new && z_out && src_idx && ld_in >= n && ld_sdf >= n, "es_upsample_step arguments");
+    return upsample_step(rays, z_in, ld_in, sdf_in, ld_sdf, N, n, n_imp, inv_s, z_new, z_out, ld_out, src_idx, (hipStream_t)stream);
+}
+int es_merge_sdf(const float* sdf_in, int ld_in, const float* sdf_new, int n_imp, const int32_t* src_idx, int ld_out, int N, int n,
+                 float* sdf_out, void* stream) {
+    ES_REQUIRE(sdf_in && sdf_new && src_idx && sdf_out && sdf_out != sdf_in, "es_merge_sdf arguments (out must not alias in)");
+    return merge_sdf(sdf_in, ld_in, sdf_new, n_imp, src_idx, ld_out, N, n, sdf_out, (hipStream_t)stream);
+}
+int es_mid_z(const float* z, int ldz, int N, int S, float sample_dist, float* mid, void* stream) {
+    ES_REQUIRE(z && mid && ldz >= S && S >= 1, "es_mid_z arguments");
+    return mid_z(z, ldz, N, S, sample_dist, mid, (hipStream_t)stream);
+}
+static inline const CompositeArgs& as_comp(const es_composite_args* a) { return *reinterpret_cast<const CompositeArgs*>(a); }
+int es_composite_forward(const es_composite_args* a, void* stream) {
+    ES_REQUIRE(a && a->rays && a->z && a->sdf && a->g_o && a->rgb && a->variance, "es_composite_forward inputs");
+    ES_REQUIRE(a->color && a->depth && a->weights && a->cdf && a->weight_max && a->eik_acc && a->wmax_idx, "es_composite_forward outputs");
+    return composite(as_comp(a), 0, (hipStream_t)stream);
+}
+int es_composite_backward(const es_composite_args* a, void* stream) {
+    ES_REQUIRE(a && a->rays && a->z && a->sdf && a->g_o && a->rgb && a->variance, "es_composite_backward inputs");
+    ES_REQUIRE(a->g_color && a->g_depth && a->g_eik && a->eik_den && a->d_sdf && a->d_go && a->d_rgb && a->d_invs_acc,
+               "es_composite_backward adjoints");
+    return composite(as_comp(a), 1, (hipStream_t)stream);
+}
+int es_march_find(const float* sdf, const float* dprop, int N, int n, float tau, float* state, int32_t* flags, float* d_pred, void* stream) {
+    ES_REQUIRE(sdf && dprop && state && flags && d_pred && n >= 2, "es_march_find arguments");
+    return march_find(sdf, dprop, N, n, tau, state, flags, d_pred, (hipStream_t)stream);
+}
+int es_secant_points(const float* rays, const float* d_pred, int N, float* x, float* t, void* stream) {
+    ES_REQUIRE(rays && d_pred && x && t, "es_secant_points arguments");
+    return secant_points(rays, d_pred, N, x, t, (hipStream_t)stream);
+}
+int es_secant_update(const float* sdf_mid, int N, float tau, float* state, float* d_pred, void* stream) {
+    ES_REQUIRE(sdf_mid && state && d_pred, "es_secant_update arguments");
+    return secant_update(sdf_mid, N, tau, state, d_pred, (hipStream_t)stream);
+}
+int es_march_finish(const float* d_pred, const int32_t* flags, int N, float* d_out, void* stream) {
+    ES_REQUIRE(d_pred && flags && d_out, "es_march_finish arguments");
+    return march_finish(d_pred, flags, N, d_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,189 @@
+"""Thin torch <-> C-ABI plumbing: allocates device buffers with torch, hands raw pointers to libendosurf_hip
+on torch's current HIP stream.  No arithmetic happens here; every method is one or a few kernel launches."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, es_composite_args, es_points, ptr, stream_ptr
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+class Engine:
+    """Per-device handle (stateless apart from the loaded library)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EndoSurfHipError(
+                f"endosurf_amd runs its hot path on an AMD GPU through HIP only (got device {device!r}); there is no CPU path")
+        self.lib = _lib.load()
+        with torch.cuda.device(self.device):
+            check(self.lib.es_init(), "es_init")
+        self.n_param = int(self.lib.es_param_floats())
+        self.n_weff = int(self.lib.es_weff_floats())
+        self.n_packed = int(self.lib.es_packed_floats())
+
+    # ---- buffers ----------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, device=self.device, dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, device=self.device, dtype=dtype)
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def weightnorm_pack(self, flat_params: torch.Tensor, use_deform: bool):
+        weff = self.empty(self.n_weff)
+        packed = self.empty(self.n_packed)
+        if not use_deform:
+            weff.zero_()
+        check(self.lib.es_weightnorm_pack(ptr(flat_params), ptr(weff), ptr(packed), int(use_deform), stream_ptr()), "es_weightnorm_pack")
+        return weff, packed
+
+    def weightnorm_backward(self, flat_params, dweff, use_deform: bool):
+        dparams = self.zeros(self.n_param)
+        check(self.lib.es_weightnorm_backward(ptr(flat_params), ptr(dweff), ptr(dparams), int(use_deform), stream_ptr()),
+              "es_weightnorm_backward")
+        return dparams
+
+    # ---- point sources ----------------------------------------------------------------------------
+    @staticmethod
+    def points(x=None, t=None, dirs=None, rays=None, z=None, n_per_ray=1, ldz=None, M=None) -> es_points:
+        p = es_points()
+        if rays is not None:
+            p.mode = 1
+            p.rays, p.z = ptr(rays), ptr(z)
+            p.n_per_ray = int(n_per_ray)
+            p.ldz = int(ldz if ldz is not None else z.shape[-1])
+            p.M = int(M if M is not None else rays.shape[0] * n_per_ray)
+            p._keep = (rays, z)
+        else:
+            p.mode = 0
+            p.x, p.t = ptr(x), ptr(t)
+            p.dirs = ptr(dirs) if dirs is not None else None
+            p.t_scalar = 1 if t.numel() == 1 and x.shape[0] != 1 else 0
+            p.n_per_ray, p.ldz = 1, 1
+            p.M = int(M if M is not None else x.shape[0])
+            p._keep = (x, t, dirs)
+        return p
+
+    def query_sdf(self, pts: es_points, weff, packed, use_deform: bool) -> torch.Tensor:
+        out = self.empty(pts.M)
+        check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), stream_ptr()), "es_query_sdf")
+        return out
+
+    # ---- per-ray kernels --------------------------------------------------------------------------
+    def ray_setup(self, rays, u, n, sample_dist, lin_mode, z, want_bounds=False):
+        N = rays.shape[0]
+        near = self.empty(N) if want_bounds else None
+        far = self.empty(N) if want_bounds else None
+        check(self.lib.es_ray_setup(ptr(rays), ptr(u) if u is not None else None, N, n, float(sample_dist), lin_mode, ptr(z),
+                                    z.shape[1], ptr(near), ptr(far), stream_ptr()), "es_ray_setup")
+        return near, far
+
+    def sample_z(self, rays, u_perturb, weff, packed, use_deform, n_samples, n_importance, up_sample_steps, upsample: bool,
+                 trace: Optional[list] = None):
+        """Coarse sampling + SDF-guided hierarchical up-sampling (reference render_rays, endosurf.py:71-110).
+        Returns z [N, S] (S = n_samples (+ n_importance))."""
+        N = rays.shape[0]
+        n = n_samples
+        sample_dist = 2.0 / n_samples
+        do_up = upsample and n_importance > 0 and up_sample_steps > 0
+        S = n + (n_importance if do_up else 0)
+        zc = self.empty(N, S)
+        self.ray_setup(rays, u_perturb, n, sample_dist, 0, zc)
+        if trace is not None:
+            trace.append(zc[:, :n].clone())
+        if not do_up:
+            return zc
+        n_imp = n_importance // up_sample_steps
+        zn = self.empty(N, S)
+        sdf_c = self.query_sdf(self.points(rays=rays, z=zc, n_per_ray=n, ldz=S), weff, packed, use_deform).view(N, n)
+        ld_sdf = n
+        sdf_a, sdf_b = self.empty(N, S), self.empty(N, S)
+        src = self.empty(N, S, dtype=torch.int32)
+        z_new = self.empty(N, n_imp)
+        for i in range(up_sample_steps):
+            check(self.lib.es_upsample_step(ptr(rays), ptr(zc), S, ptr(sdf_c), ld_sdf, N, n, n_imp, float(64 * 2 ** i), ptr(z_new),
+                                            ptr(zn), S, ptr(src), stream_ptr()), "es_upsample_step")
+            if i + 1 != up_sample_steps:
+                sdf_new = self.query_sdf(self.points(rays=rays, z=z_new, n_per_ray=n_imp, ldz=n_imp), weff, packed, use_deform)
+                dst = sdf_a if sdf_c.data_ptr() != sdf_a.data_ptr() else sdf_b
+                check(self.lib.es_merge_sdf(ptr(sdf_c), ld_sdf, ptr(sdf_new), n_imp, ptr(src), S, N, n, ptr(dst), stream_ptr()), "es_merge_sdf")
+                sdf_c, ld_sdf = dst, S
+            zc, zn = zn, zc
+            n += n_imp
+            if trace is not None:
+                trace.append(zc[:, :n].clone())
+        return zc
+
+    def mid_z(self, z, sample_dist):
+        N, S = z.shape
+        mid = self.empty(N, S)
+        check(self.lib.es_mid_z(ptr(z), S, N, S, float(sample_dist), ptr(mid), stream_ptr()), "es_mid_z")
+        return mid
+
+    def composite_args(self, rays, z, sdf, g_o, rgb, variance, sample_dist, cos_anneal) -> es_composite_args:
+        a = es_composite_args()
+        N, S = z.shape
+        a.rays, a.z, a.ldz = ptr(rays), ptr(z), S
+        a.sdf, a.g_o, a.rgb, a.variance = ptr(sdf), ptr(g_o), ptr(rgb), ptr(variance)
+        a.N, a.S, a.sample_dist, a.cos_anneal = N, S, float(sample_dist), float(cos_anneal)
+        a._keep = [rays, z, sdf, g_o, rgb, variance]
+        return a
+
+    def composite_forward(self, a: es_composite_args):
+        N, S = a.N, a.S
+        out = dict(color=self.empty(N, 3), depth=self.empty(N, 1), weights=self.empty(N, S), cdf=self.empty(N, S),
+                   weight_max=self.empty(N, 1), eik_acc=self.zeros(2), wmax_idx=self.empty(N, dtype=torch.int32))
+        for k, v in out.items():
+            setattr(a, k, ptr(v))
+        a._keep.append(out)
+        check(self.lib.es_composite_forward(C.byref(a), stream_ptr()), "es_composite_forward")
+        return out
+
+    def composite_backward(self, a: es_composite_args, g_color, g_depth, g_eik, eik_den, g_weights=None, g_cdf=None, g_wmax=None,
+                           g_gradients_o=None):
+        N, S = a.N, a.S
+        out = dict(d_sdf=self.empty(N * S), d_go=self.empty(N * S, 3), d_rgb=self.empty(N * S, 3), d_invs_acc=self.zeros(1))
+        keep = [g_color, g_depth, g_eik, eik_den, g_weights, g_cdf, g_wmax, g_gradients_o]
+        a.g_color, a.g_depth, a.g_eik, a.eik_den = ptr(g_color), ptr(g_depth), ptr(g_eik), ptr(eik_den)
+        a.g_weights = ptr(g_weights) if g_weights is not None else None
+        a.g_cdf = ptr(g_cdf) if g_cdf is not None else None
+        a.g_wmax = ptr(g_wmax) if g_wmax is not None else None
+        a.g_gradients_o = ptr(g_gradients_o) if g_gradients_o is not None else None
+        for k, v in out.items():
+            setattr(a, k, ptr(v))
+        a._keep += keep + [out]
+        check(self.lib.es_composite_backward(C.byref(a), stream_ptr()), "es_composite_backward")
+        return out
+
+    # ---- ray marching ------------------------------------------------------------------------------
+    def ray_marching(self, rays, weff, packed, use_deform, n_steps=128, n_secant_steps=8, tau=0.0):
+        """ray_marching + secant (reference endosurf.py:344-449), fixed shape. Returns d_pred [N,1]."""
+        N = rays.shape[0]
+        dprop = self.empty(N, n_steps)
+        self.ray_setup(rays, None, n_steps, 0.0, 1, dprop)
+        sdf = self.query_sdf(self.points(rays=rays, z=dprop, n_per_ray=n_steps, ldz=n_steps), weff, packed, use_deform)
+        state = self.empty(N, 4)
+        flags = self.empty(N, dtype=torch.int32)
+        d_pred = self.empty(N)
+        st = stream_ptr()
+        check(self.lib.es_march_find(ptr(sdf), ptr(dprop), N, n_steps, float(tau), ptr(state), ptr(flags), ptr(d_pred), st), "es_march_find")
+        x = self.empty(N, 3)
+        t = self.empty(N)
+        for _ in range(n_secant_steps):
+            check(self.lib.es_secant_points(ptr(rays), ptr(d_pred), N, ptr(x), ptr(t), st), "es_secant_points")
+            f_mid = self.query_sdf(self.points(x=x, t=t), weff, packed, use_deform)
+            check(self.lib.es_secant_update(ptr(f_mid), N, float(tau), ptr(state), ptr(d_pred), st), "es_secant_update")
+        d_out = self.empty(N, 1)
+        check(self.lib.es_march_finish(ptr(d_pred), ptr(flags), N, ptr(d_out), st), "es_march_finish")
+        return d_out

@@ -349,8 +349,20 @@ class OracleRenderer:
         dirs = d[:, None, :].expand(N, S, 3).reshape(-1, 3)
         t = time[:, None, None].expand(N, S, 1).reshape(-1, 1)
         pe = self.net.point_eval(pts, dirs, t, with_color=True)
-        sdf, rgb, g_o = pe["sdf"], pe["rgb"].reshape(N, S, 3), pe["g_o"]
-        inv_s = self.net.inv_s()
+        return self.composite(o, d, z, sample_dist, cos_anneal_ratio, pe["sdf"], pe["rgb"], pe["g_o"], self.net.inv_s())
+
+    def composite(self, o, d, z, sample_dist, cos_anneal_ratio, sdf, rgb, g_o, inv_s):
+        """Alpha compositing half of render_core (endosurf.py:168-213) from per-sample sdf [P,1], rgb [P,3], g_o [P,3]."""
+        N, S = z.shape
+        dz = d_over_z(d)
+        dists = z[:, 1:] - z[:, :-1]
+        dists = torch.cat([dists, torch.full_like(dists[:, :1], sample_dist)], -1)
+        mid = z + dists * 0.5
+        pts = (o[:, None, :] + dz[:, None, :] * mid[:, :, None]).reshape(-1, 3)
+        dirs = d[:, None, :].expand(N, S, 3).reshape(-1, 3)
+        sdf = sdf.reshape(-1, 1)
+        rgb = rgb.reshape(N, S, 3)
+        g_o = g_o.reshape(-1, 3)
         true_cos = (dirs * g_o).sum(-1, keepdim=True)
         r = cos_anneal_ratio
         iter_cos = -(torch.relu(-true_cos * 0.5 + 0.5) * (1.0 - r) + torch.relu(-true_cos) * r)

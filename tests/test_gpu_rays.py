@@ -1,0 +1,130 @@
+"""GPU parity of the per-ray kernels: sampling / hierarchical up-sampling, ray marching + secant, compositing fwd/bwd."""
+import numpy as np
+import pytest
+import torch
+
+import weightgen
+from oracle import endosurf_oracle as O
+from oracle_util import CASES, RENDER_CFG, T, load_case, oracle_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_for(case):
+    from endosurf_amd import params
+    from endosurf_amd.engine import Engine
+    eng = Engine("cuda")
+    seed, mode, use_deform = int(case["meta/seed"]), str(case["meta/mode"]), bool(case["meta/use_deform"])
+    flat = torch.from_numpy(params.flatten_state(weightgen.make_state(seed, mode, use_deform))).cuda()
+    weff, packed = eng.weightnorm_pack(flat, use_deform)
+    return eng, flat, weff, packed, use_deform
+
+
+def qdiff(a, b, q):
+    return float(np.quantile(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)), q))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampling_trace(name):
+    c = load_case(name)
+    eng, flat, weff, packed, use_deform = _engine_for(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    u = torch.from_numpy(c["u_perturb"]).cuda().reshape(-1).contiguous() if "u_perturb" in c else None
+    trace = []
+    z = eng.sample_z(rays, u, weff, packed, use_deform, 32, 32, 4, True, trace=trace)
+    near, far = eng.ray_setup(rays, None, 32, 2.0 / 32, 0, eng.empty(rays.shape[0], 32), want_bounds=True)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(near.cpu().numpy() - c["near64"][:, 0])) < 1e-6
+    assert np.max(np.abs(far.cpu().numpy() - c["far64"][:, 0])) < 1e-6
+    assert len(trace) == 5 and tuple(z.shape) == (rays.shape[0], 64)
+    for i, zt in enumerate(trace):
+        zt = zt.cpu().numpy()
+        ref64, ref32 = c[f"z_trace64/{i}"], c[f"z_trace/{i}"]
+        assert zt.shape == ref64.shape
+        assert np.all(np.diff(zt, axis=1) >= 0), "z must stay sorted"
+        # budget: the reference's own fp32 error against its fp64 run (inverse-CDF sampling amplifies rounding)
+        budget_q = 3 * qdiff(ref32, ref64, 0.99) + 2e-6
+        budget_max = 3 * np.max(np.abs(ref32 - ref64)) + 1e-4
+        assert qdiff(zt, ref64, 0.99) < budget_q, (i, qdiff(zt, ref64, 0.99), budget_q)
+        assert np.max(np.abs(zt - ref64)) < budget_max, i
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ray_marching(name):
+    c = load_case(name)
+    eng, flat, weff, packed, use_deform = _engine_for(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    d = eng.ray_marching(rays, weff, packed, use_deform).cpu().numpy()
+    ref64, ref32 = c["march64/d_i"], c["march/d_i"]
+    assert d.shape == ref64.shape
+    assert np.array_equal(np.isinf(d), np.isinf(ref64))
+    assert np.array_equal(d == 0, ref64 == 0)
+    fin = np.isfinite(ref64)
+    budget = 3 * np.max(np.abs(ref32[fin] - ref64[fin])) + 2e-5
+    assert np.max(np.abs(d[fin] - ref64[fin])) < budget
+
+
+def _composite_inputs(c, dtype):
+    R, _ = oracle_for(c, dtype)
+    rays = T(c["rays"], dtype)
+    z = T(c["z_trace64/4"], dtype)
+    o, d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+    N, S = z.shape
+    sd = 2.0 / 32
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((N, 1), sd, dtype=dtype)], -1)
+    mid = z + dists * 0.5
+    pts = (o[:, None] + O.d_over_z(d)[:, None] * mid[:, :, None]).reshape(-1, 3)
+    with torch.no_grad():
+        pe = R.net.point_eval(pts, d[:, None].expand(N, S, 3).reshape(-1, 3), time[:, None, None].expand(N, S, 1).reshape(-1, 1))
+    return R, rays, z, sd, pe
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_composite_forward_backward(name):
+    c = load_case(name)
+    eng, flat, weff, packed, use_deform = _engine_for(c)
+    dt = torch.float64
+    R, rays, z, sd, pe = _composite_inputs(c, dt)
+    N, S = z.shape
+    ratio = R.cos_anneal_ratio(int(c["meta/iter_step"]))
+    sdf = pe["sdf"].clone().requires_grad_(True)
+    rgb = pe["rgb"].clone().requires_grad_(True)
+    g_o = pe["g_o"].clone().requires_grad_(True)
+    var = R.net.p["deviation_network.variance"].clone().requires_grad_(True)
+    inv_s = torch.exp(var * 10.0).clamp(1e-6, 1e6)
+    ref = R.composite(rays[:, :3], rays[:, 3:6], z, sd, ratio, sdf, rgb, g_o, inv_s)
+
+    f32 = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    a = eng.composite_args(f32(rays), f32(z), f32(sdf).reshape(-1), f32(g_o), f32(rgb), f32(var).reshape(1), sd, ratio)
+    out = eng.composite_forward(a)
+    torch.cuda.synchronize()
+    eik = (out["eik_acc"][0] / (out["eik_acc"][1] + 1e-6)).item()
+    assert np.max(np.abs(out["color"].cpu().numpy() - ref["color_map"].detach().numpy())) < 3e-6
+    assert np.max(np.abs(out["depth"].cpu().numpy() - ref["depth_map"].detach().numpy())) < 5e-6
+    assert np.max(np.abs(out["weights"].cpu().numpy() - ref["weights"].detach().numpy())) < 3e-6
+    assert np.max(np.abs(out["cdf"].cpu().numpy() - ref["cdf"].detach().numpy())) < 3e-6
+    assert np.max(np.abs(out["weight_max"].cpu().numpy() - ref["weights"].detach().max(-1, keepdim=True)[0].numpy())) < 3e-6
+    assert abs(eik - float(ref["gradient_o_error"])) < 1e-5 * max(1.0, float(ref["gradient_o_error"]))
+
+    # backward: random upstream gradients on every differentiable output
+    rng = np.random.default_rng(3)
+    g = {k: torch.tensor(rng.normal(size=tuple(ref[k].shape)), dtype=dt) for k in ("color_map", "depth_map", "weights", "cdf", "gradients_o")}
+    g_eik = torch.tensor(0.7, dtype=dt)
+    g_wmax = torch.tensor(rng.normal(size=(N, 1)), dtype=dt)
+    scal = sum((ref[k] * g[k]).sum() for k in g) + ref["gradient_o_error"] * g_eik + (ref["weights"].max(-1, keepdim=True)[0] * g_wmax).sum()
+    scal.backward()
+    eik_den = (out["eik_acc"][1] + 1e-6).reshape(1).contiguous()
+    bw = eng.composite_backward(a, f32(g["color_map"]), f32(g["depth_map"]).reshape(-1), f32(g_eik).reshape(1), eik_den,
+                                g_weights=f32(g["weights"]), g_cdf=f32(g["cdf"]), g_wmax=f32(g_wmax).reshape(-1),
+                                g_gradients_o=f32(g["gradients_o"]))
+    torch.cuda.synchronize()
+
+    def rel(a_, b_):
+        b_ = b_.detach().numpy().reshape(-1)
+        return float(np.max(np.abs(a_.cpu().numpy().reshape(-1) - b_)) / (np.max(np.abs(b_)) + 1e-12))
+    assert rel(bw["d_sdf"], sdf.grad) < 2e-4, rel(bw["d_sdf"], sdf.grad)
+    assert rel(bw["d_go"], g_o.grad) < 2e-4
+    assert rel(bw["d_rgb"], rgb.grad) < 1e-5
+    # adj of inv_s -> variance: d inv_s / d var = 10 * inv_s (inside the clip)
+    dvar = bw["d_invs_acc"].item() * 10.0 * float(inv_s)
+    assert abs(dvar - float(var.grad)) < 2e-4 * abs(float(var.grad)) + 1e-6
