@@ -58,7 +58,13 @@ PROTOTYPES = {
     "es_secant_points": (_I, [_P, _P, _I, _P, _P, _P]),
     "es_secant_update": (_I, [_P, _I, _F, _P, _P, _P]),
     "es_march_finish": (_I, [_P, _P, _I, _P, _P]),
+    "es_point_workspace_floats": (C.c_int64, [_I, _I]),
+    "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
+    "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
 }
+
+PF_DEFORM, PF_COLOR, PF_SAVE = 1, 2, 4
+WS_XC, WS_J, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 
 _lib = None
 

@@ -5,12 +5,14 @@
 #include "chain_common.h"
 #include "launch.h"
 #include "ray_args.h"
+#include "workspace.h"
 
 namespace es {
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st);
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
 int upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
@@ -152,6 +154,19 @@ int es_secant_update(const float* sdf_mid, int N, float tau, float* state, float
 int es_march_finish(const float* d_pred, const int32_t* flags, int N, float* d_out, void* stream) {
     ES_REQUIRE(d_pred && flags && d_out, "es_march_finish arguments");
     return march_finish(d_pred, flags, N, d_out, (hipStream_t)stream);
+}
+
+
+int64_t es_point_workspace_floats(int M, int flags) { return M <= 0 ? 0 : (int64_t)ws_layout(M, flags).off[WS_COUNT]; }
+int64_t es_point_workspace_offset(int M, int flags, int buffer_id) {
+    if (M <= 0 || buffer_id < 0 || buffer_id >= WS_COUNT) return -1;
+    return (int64_t)ws_layout(M, flags).off[buffer_id];
+}
+int es_point_forward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode == 1 || pts->dirs, "colour evaluation needs view directions");
+    return point_forward(to_src(pts), packed, weff, ws, flags, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,415 @@
+// K4 forward: per-point network evaluation of EndoSurfNet.forward (reference endosurf.py:660-689) and
+// get_sdf_grad_from_observed_space (:581-601), restructured so that every MLP runs once:
+//   deform_fwd  DeformNetwork (:724-738) on 4 rows per point: value + 3 forward-mode tangents -> x_c and the
+//               3x3 Jacobian J = d x_c / d x  (replaces 3 forward + 4 autograd sweeps of :621-658, :581-601)
+//   sdf_fwd     SDFNetwork (:773-786) value pass (sdf, 256 features) + analytic reverse sweep for
+//               g_c = d sdf / d x_c (:603-619), then g_o = J^T g_c (identical to :581-601 up to rounding)
+//   color_fwd   ColorNetwork (:828-842) on [enc10(x_c), g_c, enc4(normalize(J d)), feat] -> sigmoid rgb
+// With PF_SAVE the layer inputs / reverse adjoints are streamed to the workspace for the backward pass.
+#include "chain_common.h"
+#include "encode.h"
+#include "launch.h"
+#include "tabs.h"
+#include "workspace.h"
+
+namespace es {
+
+struct FwdArgs {
+    PointSrc src;
+    Tabs tb;
+    const float4* packed;
+    const float* weff;
+    float* ws;
+    WsLayout L;
+    int flags;
+};
+
+__device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws + a.L.off[buf]; }
+
+// -------------------------------------------------------------------------------------------------------------
+// deformation network, value + 3 tangents.  Tile = 16 points = 64 rows (row 4p + c).
+__global__ __launch_bounds__(NTHREADS) void k_deform_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* px = scr;         // [3][16]
+    float* pt = scr + 48;    // [16]
+    float* red = scr + 64;   // [4][3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt0 = blockIdx.x * 16;
+    const size_t grow0 = (size_t)pt0 * 4;
+    const bool save = a.flags & PF_SAVE;
+    const size_t rows4 = (size_t)a.L.Mp * 4;
+
+    if (tid < 16) {
+        float x[3], t, d[3];
+        load_point(a.src, pt0 + tid, x, t, d);
+        px[tid] = x[0]; px[16 + tid] = x[1]; px[32 + tid] = x[2]; pt[tid] = t;
+    }
+    zero_rows(aux, 0, 56, tid);
+    __syncthreads();
+    {   // encoding rows: value row 4p, tangent rows 4p+1+c (d/dx_c); time part has no tangent
+        const int p = tid & 15;
+        for (int item = tid >> 4; item < 25; item += 16) {
+            if (item < 18) {
+                const int c = item % 3, i = item / 3;
+                const float f = (float)(1 << i);
+                float s, co;
+                sincosf(px[c * 16 + p] * f, &s, &co);
+                aux[swz(enc_index(3, i, 0, c), 4 * p)] = s;
+                aux[swz(enc_index(3, i, 1, c), 4 * p)] = co;
+                aux[swz(enc_index(3, i, 0, c), 4 * p + 1 + c)] = f * co;
+                aux[swz(enc_index(3, i, 1, c), 4 * p + 1 + c)] = -f * s;
+            } else if (item < 24) {
+                const int i = item - 18;
+                float s, co;
+                sincosf(pt[p] * (float)(1 << i), &s, &co);
+                aux[swz(39 + enc_index(1, i, 0, 0), 4 * p)] = s;
+                aux[swz(39 + enc_index(1, i, 1, 0), 4 * p)] = co;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { aux[swz(c, 4 * p)] = px[c * 16 + p]; aux[swz(c, 4 * p + 1 + c)] = 1.f; }
+                aux[swz(39, 4 * p)] = pt[p];
+            }
+        }
+    }
+    __syncthreads();
+    if (save) {   // u_0 rows for the weight-gradient GEMM: [4Mp][64], 56 columns written
+        float* U0 = wsb(a, WS_D_U0);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 56; k += 4) U0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+    }
+
+    float* U = wsb(a, WS_D_U);
+    auto epi = [&](f32x16(&acc)[2][2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l];
+        float* Ul = U + (size_t)l * rows4 * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            if (l == 3 && col >= 204) {
+                lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
+            } else {
+                const float av = v[0] + bias[col];
+                const bool m = av > 0.f;                          // ReLU mask of the value row gates its tangents
+                v[0] = m ? av : 0.f; v[1] = m ? v[1] : 0.f; v[2] = m ? v[2] : 0.f; v[3] = m ? v[3] : 0.f;
+            }
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(Ul, grow0, 256, row, col, v);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
+        epi(acc, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
+        __syncthreads();
+        epi(acc, l);
+        __syncthreads();
+    }
+    smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 192) {
+        const int i = tid >> 6, row = tid & 63, p = row >> 2, c = row & 3;
+        const float val = smalln_reduce<3>(red, i, row);
+        const size_t gp = (size_t)(pt0 + p);
+        if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 16 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
+        else wsb(a, WS_J)[gp * 9 + i * 3 + (c - 1)] = val + (i == c - 1 ? 1.f : 0.f);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// SDF network: value pass + reverse sweep.  Tile = 64 points.
+__global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* px = scr;          // [3][64]
+    float* red = scr + 256;   // [4][1][64]
+    float* gcv = scr + 512;   // [3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TM;
+    const size_t grow0 = (size_t)row0;
+    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM, color = a.flags & PF_COLOR;
+    const size_t Mp = (size_t)a.L.Mp;
+
+    if (tid < 64) {
+        if (deform) {
+            const float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
+            px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
+        } else {
+            float x[3], t, d[3];
+            load_point(a.src, row0 + tid, x, t, d);
+            px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2];
+            float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
+            xc[0] = x[0]; xc[1] = x[1]; xc[2] = x[2];
+        }
+    }
+    __syncthreads();
+    encode3<6>(aux, 0, px, tid);
+    zero_rows(aux, 39, 40, tid);
+    __syncthreads();
+    if (save) {
+        float* S0 = wsb(a, WS_S_S0);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 40; k += 4) S0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+    }
+    float* SACT = wsb(a, WS_S_ACT);
+    auto epi = [&](f32x16(&acc)[2][2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + l];
+        float* Sl = SACT + (size_t)l * Mp * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(Sl, grow0, 256, row, col, v);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
+        epi(acc, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
+        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
+        __syncthreads();
+        epi(acc, l);
+        __syncthreads();
+    }
+    // last layer: 256 geometry features (MFMA) + sdf (row 0, VALU)
+    if (color) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[SF8F], 0, 2 * wave, lane);
+        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + 8] + 1;
+        float* feat = wsb(a, WS_FEAT);
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += b;
+            g_store_quad(feat, grow0, 256, row, col, v);
+        });
+    }
+    smalln_partial<1>(mainT, a.weff + a.tb.woff[NET_S * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 64) wsb(a, WS_SDF)[grow0 + tid] = smalln_reduce<1>(red, 0, tid) + a.weff[a.tb.boff[NET_S * LAYERS + 8]];
+
+    // ---- reverse sweep: rho_l = d sdf / d z_l ----
+    float* RHO = wsb(a, WS_S_RHO);
+    {   // rho_7 = softplus'(z_7) * W8[0,:]   (mainT still holds s_8 = softplus(z_7))
+        const float* w8 = a.weff + a.tb.woff[NET_S * LAYERS + 8];
+        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+            float v[4];
+            lds_load_quad(mainT, col, row, v);
+            const float w = w8[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(v[i]) * w;
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(RHO + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+        });
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);       // adjoint of s_l
+        f32x16 accA[1][1];
+        if (l == 4) {
+            acc_zero(accA);
+            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
+        }
+        __syncthreads();
+        const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4];
+            g_load_quad(Sl, grow0, 256, row, col, s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(s[i]);
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(RHO + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
+        });
+        if (l == 4)
+            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+        __syncthreads();
+    }
+    {
+        f32x16 accA[1][1];
+        acc_zero(accA);
+        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
+        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+    }
+    __syncthreads();
+    if (save) {
+        float* AE = wsb(a, WS_S_ADJEPS);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 40; k += 4) AE[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+    }
+    if (tid < 192) {   // g_c[j] = sum_k adj_eps[k] * d enc_k / d x_j
+        const int j = tid >> 6, row = tid & 63;
+        const float x = px[j * 64 + row];
+        float g = aux[swz(j, row)];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(x * f, &s, &co);
+            g += f * (aux[swz(enc_index(3, i, 0, j), row)] * co - aux[swz(enc_index(3, i, 1, j), row)] * s);
+        }
+        gcv[j * 64 + row] = g;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        const float g0 = gcv[tid], g1 = gcv[64 + tid], g2 = gcv[128 + tid];
+        float* gc = wsb(a, WS_GC) + gp * 3;
+        gc[0] = g0; gc[1] = g1; gc[2] = g2;
+        float* go = wsb(a, WS_GO) + gp * 3;
+        if (deform) {
+            const float* J = wsb(a, WS_J) + gp * 9;      // g_o[k] = sum_i J[i][k] g_c[i]
+            go[0] = J[0] * g0 + J[3] * g1 + J[6] * g2;
+            go[1] = J[1] * g0 + J[4] * g1 + J[7] * g2;
+            go[2] = J[2] * g0 + J[5] * g1 + J[8] * g2;
+        } else {
+            go[0] = g0; go[1] = g1; go[2] = g2;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// colour network.  Tile = 64 points.
+__global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* px = scr;          // [3][64] x_c
+    float* pd = scr + 192;    // [3][64] d_c
+    float* pg = scr + 384;    // [3][64] g_c
+    float* red = scr + 576;   // [4][3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TM;
+    const size_t grow0 = (size_t)row0;
+    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM;
+    const size_t Mp = (size_t)a.L.Mp;
+    const float* feat = wsb(a, WS_FEAT);
+
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        float x[3], t, d[3];
+        load_point(a.src, row0 + tid, x, t, d);
+        const float* xc = wsb(a, WS_XC) + gp * 3;
+        const float* gc = wsb(a, WS_GC) + gp * 3;
+        px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
+        pg[tid] = gc[0]; pg[64 + tid] = gc[1]; pg[128 + tid] = gc[2];
+        float v0 = d[0], v1 = d[1], v2 = d[2];
+        if (deform) {
+            const float* J = wsb(a, WS_J) + gp * 9;      // d_c = J d / (|J d| + 1e-10)   endosurf.py:684-685
+            v0 = J[0] * d[0] + J[1] * d[1] + J[2] * d[2];
+            v1 = J[3] * d[0] + J[4] * d[1] + J[5] * d[2];
+            v2 = J[6] * d[0] + J[7] * d[1] + J[8] * d[2];
+        }
+        const float inv = 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
+        pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
+    }
+    __syncthreads();
+    encode3<10>(aux, 0, px, tid);       // rows 0..62
+    if (tid < 192) aux[swz(63 + (tid >> 6), tid & 63)] = pg[tid];
+    encode3<4>(aux, 66, pd, tid);       // rows 66..92
+    zero_rows(aux, 93, 96, tid);
+    load_tile_256(mainT, feat, grow0, 256, tid);
+    __syncthreads();
+    if (save) {
+        float* CIN = wsb(a, WS_C_IN);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 96; k += 4) CIN[(grow0 + r) * 128 + k] = aux[swz(k, r)];
+    }
+    float* CH = wsb(a, WS_C_H);
+    auto epi = [&](f32x16(&acc)[2][2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_C * LAYERS + l];
+        float* Hl = CH + (size_t)l * Mp * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(Hl, grow0, 256, row, col, v);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0F], 0, 2 * wave, lane);
+        gemm_seg<12, 2, 2>(acc, aux, a.packed + a.tb.segoff[CF0S], 0, 2 * wave, lane);
+        __syncthreads();
+        epi(acc, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        if (l != 4) {
+            const int seg = l < 4 ? CF1 + (l - 1) : CF5 + (l - 5);
+            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
+        } else {   // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
+            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4H], 0, 2 * wave, lane);
+            __syncthreads();
+            load_tile_256(mainT, feat, grow0, 256, tid);
+            __syncthreads();
+            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4F], 0, 2 * wave, lane);
+            gemm_seg<12, 2, 2>(acc, aux, a.packed + a.tb.segoff[CF4S], 0, 2 * wave, lane);
+        }
+        __syncthreads();
+        epi(acc, l);
+        __syncthreads();
+    }
+    smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_C * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 192) {
+        const int i = tid >> 6, row = tid & 63;
+        const float y = smalln_reduce<3>(red, i, row) + a.weff[a.tb.boff[NET_C * LAYERS + 8] + i];
+        wsb(a, WS_RGB)[(grow0 + row) * 3 + i] = 1.f / (1.f + expf(-y));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (int e = allow_big_lds(k_deform_fwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd, LDS_BYTES)) return e;
+        attr_done = true;
+    }
+    if (src.M <= 0) return ST_OK;
+    FwdArgs a;
+    a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
+    a.L = ws_layout(src.M, flags); a.flags = flags;
+    const int Mp = a.L.Mp;
+    if (flags & PF_DEFORM) hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
+    if (flags & PF_COLOR) hipLaunchKernelGGL(k_color_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
+    return hip_last("point_forward");
+}
+
+}  // namespace es

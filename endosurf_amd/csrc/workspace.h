@@ -1,0 +1,74 @@
+// Layout of the per-call point-evaluation workspace (one caller-owned fp32 device buffer).
+//
+// All per-point tensors are row-major [Mp][ld] with Mp = M rounded up to a multiple of 64 so that tiles never
+// need row guards; rows >= M carry finite junk in forward buffers and exact zeros in every adjoint buffer.
+// Deformation-network buffers have 4 rows per point: row 4p = value, rows 4p+1..3 = d/dx_0..2 tangents.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace es {
+
+constexpr int PF_DEFORM = 1;   // deformation network present (use_deform)
+constexpr int PF_COLOR = 2;    // evaluate the colour network (render_core) — off for errorondepth / surface_neighbour_error
+constexpr int PF_SAVE = 4;     // keep activations for the backward pass (training)
+
+enum WsBuf : int {
+    // forward outputs
+    WS_XC, WS_J, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB,
+    // forward saves
+    WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them)
+    WS_D_U0,       // [4Mp][64]     deform encoding rows (52 valid)
+    WS_D_U,        // [8][4Mp][256] u_1..u_8
+    WS_S_S0,       // [Mp][64]      enc6(x_c) (39 valid)
+    WS_S_RHO,      // [8][Mp][256]  d sdf / d z_0..7
+    WS_S_ADJEPS,   // [Mp][64]      d sdf / d enc6(x_c)
+    WS_C_IN,       // [Mp][128]     colour input small part (93 valid)
+    WS_C_H,        // [8][Mp][256]  h_1..h_8
+    // backward buffers
+    WS_C_Y,        // [8][Mp][256]  adjoints of colour pre-activations y_0..7
+    WS_C_Y8,       // [Mp][4]
+    WS_FEATBAR,    // [Mp][256]
+    WS_XCBAR_C, WS_GCBAR_C, WS_JBAR_C,
+    WS_S_TAU0,     // [Mp][64]
+    WS_S_TAU,      // [8][Mp][256]  tau_1..tau_8
+    WS_S_ZB,       // [8][Mp][256]  second-order terms, overwritten in place by the adjoints of z_0..7
+    WS_XCBAR, WS_JBAR,
+    WS_D_A,        // [8][4Mp][256] adjoints of deform pre-activations a_0..7
+    WS_D_A8,       // [4Mp][4]
+    WS_COUNT
+};
+
+struct WsLayout {
+    size_t off[WS_COUNT + 1];
+    int Mp;
+};
+
+inline int round_up64(int m) { return (m + 63) / 64 * 64; }
+
+inline WsLayout ws_layout(int M, int flags) {
+    WsLayout L;
+    const size_t Mp = (size_t)round_up64(M);
+    L.Mp = (int)Mp;
+    const bool def = flags & PF_DEFORM, col = flags & PF_COLOR, save = flags & PF_SAVE;
+    size_t sz[WS_COUNT] = {0};
+    sz[WS_XC] = Mp * 3; sz[WS_J] = Mp * 9; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
+    sz[WS_FEAT] = col ? Mp * 256 : 0; sz[WS_RGB] = col ? Mp * 3 : 0;
+    sz[WS_S_ACT] = 8 * Mp * 256;
+    if (save) {
+        if (def) { sz[WS_D_U0] = 4 * Mp * 64; sz[WS_D_U] = 8 * 4 * Mp * 256; sz[WS_D_A] = 8 * 4 * Mp * 256; sz[WS_D_A8] = 4 * Mp * 4; }
+        sz[WS_S_S0] = Mp * 64; sz[WS_S_RHO] = 8 * Mp * 256; sz[WS_S_ADJEPS] = Mp * 64;
+        sz[WS_S_TAU0] = Mp * 64; sz[WS_S_TAU] = 8 * Mp * 256; sz[WS_S_ZB] = 8 * Mp * 256;
+        sz[WS_XCBAR] = Mp * 3; sz[WS_JBAR] = Mp * 9;
+        if (col) {
+            sz[WS_C_IN] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
+            sz[WS_FEATBAR] = Mp * 256; sz[WS_XCBAR_C] = Mp * 3; sz[WS_GCBAR_C] = Mp * 3; sz[WS_JBAR_C] = Mp * 9;
+        }
+    }
+    size_t o = 0;
+    for (int i = 0; i < WS_COUNT; ++i) { L.off[i] = o; o += (sz[i] + 63) / 64 * 64; }   // keep every buffer 256-B aligned
+    L.off[WS_COUNT] = o;
+    return L;
+}
+
+}  // namespace es

@@ -187,3 +187,31 @@ class Engine:
         d_out = self.empty(N, 1)
         check(self.lib.es_march_finish(ptr(d_pred), ptr(flags), N, ptr(d_out), st), "es_march_finish")
         return d_out
+
+
+class PointCtx:
+    """Workspace of one fused point evaluation + typed views of its outputs."""
+    _OUT = {"xc": (_lib.WS_XC, 3), "J": (_lib.WS_J, 9), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
+            "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3)}
+
+    def __init__(self, eng: "Engine", pts, flags: int):
+        self.eng, self.pts, self.flags, self.M = eng, pts, flags, pts.M
+        self.Mp = (self.M + 63) // 64 * 64
+        n = int(eng.lib.es_point_workspace_floats(self.M, flags))
+        self.ws = eng.empty(max(n, 1))
+
+    def view(self, name):
+        buf, width = self._OUT[name]
+        off = int(self.eng.lib.es_point_workspace_offset(self.M, self.flags, buf))
+        v = self.ws[off:off + self.Mp * width].view(self.Mp, width)[:self.M]
+        return v
+
+
+def _point_forward(self, pts, weff, packed, flags: int) -> PointCtx:
+    ctx = PointCtx(self, pts, flags)
+    ctx.keep = (weff, packed)
+    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, stream_ptr()), "es_point_forward")
+    return ctx
+
+
+Engine.point_forward = _point_forward
