@@ -1,0 +1,452 @@
+"""Drop-in replacement for the reference's ``src.renderer.endosurf.EndoSurfRenderer`` (endosurf.py:14-521),
+backed by libendosurf_hip (hand-written HIP for gfx950) instead of ATen op chains.
+
+Same constructor (``render_cfg``, ``net_cfg``, ``device``), same public methods and return dictionaries, same
+``state_dict`` key names (``model.{deform,sdf,color}_network.net.{l}.{bias,weight_g,weight_v}``,
+``model.deviation_network.variance``) so reference checkpoints load unchanged.  Host code is orchestration only:
+every tensor op of the hot path runs inside the C-ABI library; there is no PyTorch/CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, params as P
+from .engine import Engine, PointCtx
+
+# architecture every reference EndoSurf config uses (configs/endosurf/**: only ``use_deform`` varies)
+_ARCH = {
+    "deform_network": dict(n_layers=9, hidden_dim=256, skips=[4], out_dim=3,
+                           enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=6),
+                           enc_time_cfg=dict(enc_type="frequency", input_dim=1, multires=6)),
+    "sdf_network": dict(n_layers=9, hidden_dim=256, skips=[4], out_dim=257,
+                        enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=6)),
+    "color_network": dict(n_layers=9, hidden_dim=256, skips=[4], out_dim=3, feat_dim=256,
+                          enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=10),
+                          enc_dir_cfg=dict(enc_type="frequency", input_dim=3, multires=4)),
+}
+
+
+def _check_arch(net_cfg: dict):
+    """The kernels are specialised for the one architecture the reference ships; anything else fails loudly."""
+    for net, want in _ARCH.items():
+        if net == "deform_network" and not net_cfg.get("use_deform", True):
+            continue
+        got = net_cfg[net]
+        for k, v in want.items():
+            g = got.get(k, v)
+            if isinstance(v, dict):
+                g = {kk: g.get(kk) for kk in v}
+            if g != v:
+                raise NotImplementedError(
+                    f"endosurf_amd kernels are specialised for net.{net}.{k} = {v!r} (all reference EndoSurf configs); got {g!r}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parameter holders (views into one flat fp32 device buffer whose layout is owned by csrc/arch.h)
+# ---------------------------------------------------------------------------------------------------------------
+class WNLinear(nn.Module):
+    """Parameters of one weight-normed nn.Linear, reference names/shapes: bias[N], weight_g[N,1], weight_v[N,K]."""
+
+    def __init__(self, flat: torch.Tensor, lay: dict, prefix: str):
+        super().__init__()
+        for name in ("bias", "weight_g", "weight_v"):
+            off, shape = lay[f"{prefix}.{name}"]
+            n = int(np.prod(shape))
+            self.register_parameter(name, nn.Parameter(flat[off:off + n].view(shape)))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("layers are evaluated by the fused HIP kernels, not individually")
+
+
+class _MLP(nn.Module):
+    def __init__(self, flat, lay, net_name):
+        super().__init__()
+        self.net = nn.ModuleList([WNLinear(flat, lay, f"{net_name}.net.{l}") for l in range(9)])
+
+
+class DeformNetwork(_MLP):
+    pass
+
+
+class SDFNetwork(_MLP):
+    pass
+
+
+class ColorNetwork(_MLP):
+    pass
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, flat, lay):
+        super().__init__()
+        off, _ = lay["deviation_network.variance"]
+        self.register_parameter("variance", nn.Parameter(flat[off:off + 1].view(())))
+
+
+def _reference_style_init(flat: torch.Tensor, lay: dict, net_cfg: dict):
+    """Same initial distributions (and, under the same torch seed, the same draws in the same order) as the reference:
+    build_mlp_idr / build_mlp_nerf (utils.py:11-111) -> nn.Linear default init, geometric init for the SDF network
+    (bias 0.8), then weight_norm's g = ||W||_row, v = W; SingleVarianceNetwork init_val (endosurf.py:845-848)."""
+    sdf_bias = float(net_cfg["sdf_network"].get("geometric_init_bias", 0.8))
+    geometric = bool(net_cfg["sdf_network"].get("geometric_init", True))
+    order = (["deform_network"] if net_cfg.get("use_deform", True) else []) + ["sdf_network", "color_network"]
+    with torch.no_grad():
+        for net in order:
+            for l in range(9):
+                _, (n_out, n_in) = lay[f"{net}.net.{l}.weight_v"]
+                lin = nn.Linear(n_in, n_out)
+                W, b = lin.weight.data, lin.bias.data
+                if net == "sdf_network" and geometric:
+                    in_dim = 39
+                    if l == 8:
+                        nn.init.normal_(W, mean=math.sqrt(math.pi) / math.sqrt(n_in), std=1e-4)
+                        nn.init.constant_(b, -sdf_bias)
+                    elif l == 0:
+                        nn.init.constant_(b, 0.0)
+                        nn.init.constant_(W[:, 3:], 0.0)
+                        nn.init.normal_(W[:, :3], 0.0, math.sqrt(2) / math.sqrt(n_out))
+                    elif l == 4:
+                        nn.init.constant_(b, 0.0)
+                        nn.init.normal_(W, 0.0, math.sqrt(2) / math.sqrt(n_out))
+                        nn.init.constant_(W[:, -(in_dim - 3):], 0.0)
+                    else:
+                        nn.init.constant_(b, 0.0)
+                        nn.init.normal_(W, 0.0, math.sqrt(2) / math.sqrt(n_out))
+                for name, val in (("bias", b), ("weight_g", W.norm(dim=1, keepdim=True)), ("weight_v", W)):
+                    off, shape = lay[f"{net}.net.{l}.{name}"]
+                    flat[off:off + val.numel()].copy_(val.reshape(-1))
+        off, _ = lay["deviation_network.variance"]
+        flat[off] = float(net_cfg["deviation_network"]["init_val"])
+
+
+class EndoSurfNet(nn.Module):
+    """Parameter container mirroring the reference EndoSurfNet (endosurf.py:524-568)."""
+
+    def __init__(self, net_cfg: dict, device):
+        super().__init__()
+        _check_arch(net_cfg)
+        self.bound = net_cfg["bound"]
+        self.use_deform = bool(net_cfg["use_deform"])
+        lay = P.layout()
+        n = int(_lib.load().es_param_floats())
+        flat_cpu = torch.zeros(n)
+        _reference_style_init(flat_cpu, lay, net_cfg)
+        self._flat = flat_cpu.to(device)
+        if self.use_deform:
+            self.deform_network = DeformNetwork(self._flat, lay, "deform_network")
+        self.sdf_network = SDFNetwork(self._flat, lay, "sdf_network")
+        self.color_network = ColorNetwork(self._flat, lay, "color_network")
+        self.deviation_network = SingleVarianceNetwork(self._flat, lay)
+        self._layout = lay
+
+    def get_train_params(self):
+        out = {}
+        if self.use_deform:
+            out["deform_network"] = list(self.deform_network.parameters())
+        out["sdf_network"] = list(self.sdf_network.parameters())
+        out["color_network"] = list(self.color_network.parameters())
+        out["deviation_network"] = list(self.deviation_network.parameters())
+        return out
+
+    def load_checkpoints(self, ckpt):
+        if self.use_deform:
+            self.deform_network.load_state_dict(ckpt["deform_network"])
+        self.sdf_network.load_state_dict(ckpt["sdf_network"])
+        self.color_network.load_state_dict(ckpt["color_network"])
+        self.deviation_network.load_state_dict(ckpt["deviation_network"])
+
+    def save_checkpoint(self):
+        ckpt = {}
+        if self.use_deform:
+            ckpt["deform_network"] = self.deform_network.state_dict()
+        ckpt["sdf_network"] = self.sdf_network.state_dict()
+        ckpt["color_network"] = self.color_network.state_dict()
+        ckpt["deviation_network"] = self.deviation_network.state_dict()
+        return ckpt
+
+    def ordered_params(self):
+        """(key, Parameter) in flat-buffer order, variance excluded."""
+        out = []
+        for net in P.NET_NAMES:
+            if net == "deform_network" and not self.use_deform:
+                continue
+            mod = getattr(self, net)
+            for l in range(9):
+                for name in ("bias", "weight_g", "weight_v"):
+                    out.append((f"{net}.net.{l}.{name}", getattr(mod.net[l], name)))
+        return out
+
+    def forward(self, *a, **k):
+        raise RuntimeError("use EndoSurfRenderer; the network is evaluated by fused HIP kernels")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# autograd glue
+# ---------------------------------------------------------------------------------------------------------------
+class _PackFn(torch.autograd.Function):
+    """(bias, weight_g, weight_v)* -> effective-weight buffer (+ packed MFMA fragments as a side product)."""
+
+    @staticmethod
+    def forward(ctx, model: EndoSurfNet, eng: Engine, *plist):
+        weff, packed = eng.weightnorm_pack(model._flat, model.use_deform)
+        ctx.model, ctx.eng = model, eng
+        ctx.mark_non_differentiable(packed)
+        return weff, packed
+
+    @staticmethod
+    def backward(ctx, dweff, _dpacked):
+        model, eng = ctx.model, ctx.eng
+        model._pack_cache = None
+        dflat = eng.weightnorm_backward(model._flat, dweff.contiguous(), model.use_deform)
+        grads = []
+        for key, p in model.ordered_params():
+            off, shape = model._layout[key]
+            grads.append(dflat[off:off + p.numel()].view(p.shape))
+        return (None, None, *grads)
+
+
+class _PointEvalFn(torch.autograd.Function):
+    """Fused per-point evaluation (sdf, g_o[, rgb]) with hand-written backward to the effective weights."""
+
+    @staticmethod
+    def forward(ctx, weff, packed, eng: Engine, pts, flags: int):
+        # grad mode is disabled inside Function.forward; the caller passes the save decision through ``flags``
+        pctx = eng.point_forward(pts, weff, packed, flags)
+        ctx.pctx, ctx.eng, ctx.weff, ctx.packed = pctx, eng, weff, packed
+        outs = [pctx.view("sdf"), pctx.view("go")]
+        if flags & _lib.PF_COLOR:
+            outs.append(pctx.view("rgb"))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_go, d_rgb=None):
+        eng, pctx = ctx.eng, ctx.pctx
+        if not (pctx.flags & _lib.PF_SAVE):
+            raise RuntimeError("point evaluation was run without PF_SAVE; cannot backpropagate")
+        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, d_rgb)
+        return dweff, None, None, None, None
+
+
+class _RenderFn(torch.autograd.Function):
+    """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing."""
+
+    @staticmethod
+    def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int):
+        N, S = z.shape
+        mid = eng.mid_z(z, sample_dist)
+        pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S)
+        pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR)
+        a = eng.composite_args(rays, z, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), variance.detach().reshape(1),
+                               sample_dist, cos_anneal)
+        out = eng.composite_forward(a)
+        eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
+        eik = (out["eik_acc"][0] / eik_den[0])
+        ctx.eng, ctx.pctx, ctx.a, ctx.out, ctx.eik_den = eng, pctx, a, out, eik_den
+        ctx.weff, ctx.packed, ctx.variance = weff, packed, variance
+        ctx.NS = (N, S)
+        gradients_o = pctx.view("go").view(N, S, 3)
+        ctx.mark_non_differentiable(out["wmax_idx"])
+        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"]
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _):
+        eng, pctx = ctx.eng, ctx.pctx
+        if not (pctx.flags & _lib.PF_SAVE):
+            raise RuntimeError("render was run without saved activations; cannot backpropagate")
+        N, S = ctx.NS
+        z = lambda g, *shape: (g.contiguous() if g is not None else eng.zeros(*shape))
+        bw = eng.composite_backward(ctx.a, z(g_color, N, 3), z(g_depth, N, 1).view(-1), z(g_eik, 1).reshape(1), ctx.eik_den,
+                                    g_weights=g_weights.contiguous() if g_weights is not None else None,
+                                    g_cdf=g_cdf.contiguous() if g_cdf is not None else None,
+                                    g_wmax=g_wmax.contiguous().view(-1) if g_wmax is not None else None,
+                                    g_gradients_o=g_go.contiguous() if g_go is not None else None)
+        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, bw["d_sdf"], bw["d_go"], bw["d_rgb"])
+        # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852)
+        var = ctx.variance.detach()
+        e = torch.exp(var * 10.0)
+        inside = ((e >= 1e-6) & (e <= 1e6)).to(e.dtype)
+        dvar = (bw["d_invs_acc"][0] * 10.0 * e * inside).reshape(ctx.variance.shape)
+        return dweff, None, dvar, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class EndoSurfRenderer(nn.Module):
+    """EndoSurf renderer (drop-in for reference src/renderer/endosurf.py:14-521)."""
+
+    def __init__(self, render_cfg, net_cfg, device="cuda"):
+        super().__init__()
+        self.render_cfg = render_cfg
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.dtype = torch.float32
+        self.net_cfg = net_cfg
+        self.engine = Engine(self.device)          # raises if not an AMD GPU / library missing: no fallback
+        self.model = EndoSurfNet(net_cfg, self.device)
+        self.model._pack_cache = None
+        self.anneal_end = render_cfg["anneal_end"]
+        self.n_samples = render_cfg["n_samples"]
+        self.perturb = render_cfg["perturb"]
+        self.n_importance = render_cfg["n_importance"]
+        self.important_begin_iter = render_cfg["important_begin_iter"]
+        self.up_sample_steps = render_cfg["up_sample_steps"]
+        self.net_chunk = render_cfg["net_chunk"]
+        self.use_deform = self.model.use_deform
+
+    # ---- reference API: parameters / checkpoints -------------------------------------------------------------
+    def get_train_params(self):
+        return self.model.get_train_params()
+
+    def load_checkpoint(self, ckpt):
+        self.model.load_checkpoints(ckpt)
+
+    def save_checkpoint(self):
+        return self.model.save_checkpoint()
+
+    def get_cos_anneal_ratio(self, iter_step):
+        if self.anneal_end == 0.0:
+            return 1.0
+        return float(np.min([1.0, iter_step / self.anneal_end]))
+
+    # ---- weights: weight-norm + MFMA packing once per parameter version ------------------------------------------
+    def _weights(self):
+        m = self.model
+        plist = [p for _, p in m.ordered_params()]
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+        key = (tuple(p._version for p in plist), want_grad)
+        c = m._pack_cache
+        if c is not None and c[0] == key:
+            return c[1], c[2]
+        if want_grad:
+            weff, packed = _PackFn.apply(m, self.engine, *plist)
+        else:
+            with torch.no_grad():
+                weff, packed = self.engine.weightnorm_pack(m._flat, m.use_deform)
+        m._pack_cache = (key, weff, packed)
+        return weff, packed
+
+    def _flags(self, weff):
+        f = _lib.PF_DEFORM if self.use_deform else 0
+        if weff.requires_grad and torch.is_grad_enabled():
+            f |= _lib.PF_SAVE
+        return f
+
+    @staticmethod
+    def _rays32(rays):
+        return rays.detach().to(torch.float32).contiguous()
+
+    # ---- reference API: rendering ------------------------------------------------------------------------------------
+    def forward(self, rays, **kwargs):
+        return self.render_rays(rays, **kwargs)
+
+    def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, **kwargs):
+        """reference render_rays (endosurf.py:60-132).  ``u_perturb`` ([N] or [N,1] uniform draws) may be supplied to
+        make the stratified jitter reproducible; otherwise it is drawn with torch.rand on the device like the reference."""
+        rays = self._rays32(rays)
+        n_rays = rays.shape[0]
+        weff, packed = self._weights()
+        perturb = self.perturb if perturb_overwrite is None else perturb_overwrite
+        u = None
+        if perturb:
+            u = u_perturb if u_perturb is not None else torch.rand([n_rays, 1], device=self.device)
+            u = u.detach().to(torch.float32).reshape(-1).contiguous()
+        upsample = iter_step >= self.important_begin_iter and self.n_importance > 0
+        with torch.no_grad():
+            z = self.engine.sample_z(rays, u, weff.detach(), packed, self.use_deform, self.n_samples, self.n_importance,
+                                     self.up_sample_steps, upsample)
+        sample_dist = 2.0 / self.n_samples
+        ret = self.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist,
+                               cos_anneal_ratio=self.get_cos_anneal_ratio(iter_step), eval=eval, _rays=rays)
+        n_samples = z.shape[1]
+        return {
+            "color_map": ret["color_map"],
+            "depth_map": ret["depth_map"],
+            "gradients_o": ret["gradients_o"],
+            "gradient_o_error": ret["gradient_o_error"],
+            "weights": ret["weights"],
+            "weight_max": ret["weight_max"],
+            "cdf": ret["cdf"],
+            "s_val": ret["s_val"].reshape(1, 1).expand(n_rays, n_samples).mean(dim=-1, keepdim=True),
+        }
+
+    def render_core(self, rays_o, rays_d, time, z_vals, sample_dist, cos_anneal_ratio=0.0, eval=False, _rays=None):
+        """reference render_core (endosurf.py:134-213)."""
+        if _rays is None:
+            n = rays_o.shape[0]
+            _rays = torch.cat([rays_o, rays_d, torch.zeros(n, 2, device=self.device), time.reshape(n, 1)], -1).to(torch.float32).contiguous()
+        weff, packed = self._weights()
+        var = self.model.deviation_network.variance
+        z = z_vals.detach().to(torch.float32).contiguous()
+        color, depth, g_o, eik, weights, wmax, cdf, _ = _RenderFn.apply(weff, packed, var, self.engine, _rays, z, float(sample_dist),
+                                                                     float(cos_anneal_ratio), self._flags(weff))
+        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        return {"color_map": color, "depth_map": depth, "gradients_o": g_o, "gradient_o_error": eik, "cdf": cdf,
+                "weights": weights, "weight_max": wmax, "s_val": 1.0 / inv_s}
+
+    # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
+    def _point_eval(self, x, t, dirs=None):
+        weff, packed = self._weights()
+        pts = self.engine.points(x=x.detach().to(torch.float32).contiguous(), t=t.detach().to(torch.float32).reshape(-1).contiguous(),
+                                 dirs=dirs)
+        sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, self._flags(weff))
+        return sdf, g_o
+
+    def errorondepth(self, rays, d_gt, mask, iter_step=0):
+        rays = self._rays32(rays)
+        rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+        rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
+        pts = (rays_o + rays_d_z * d_gt).reshape(-1, 3)
+        sdf, gradient_o = self._point_eval(pts, time)
+        true_cos = (rays_d * gradient_o).sum(-1, keepdim=True)
+        relu_cos = torch.relu(true_cos)
+        pts_norm = torch.linalg.norm(pts.detach(), ord=2, dim=-1, keepdim=True)
+        inside_masksphere = (pts_norm < 1.0).to(self.dtype) * mask
+        sdf = inside_masksphere * sdf
+        denom = inside_masksphere.sum() + 1e-6
+        sdf_error = sdf.abs().sum() / denom
+        angle_error = relu_cos.abs().sum() / denom          # not masked, like the reference (endosurf.py:315)
+        return sdf_error, angle_error, inside_masksphere
+
+    def ray_marching(self, rays, tau=0.0, n_steps=(128, 129), n_secant_steps=8, max_points=64000):
+        """reference ray_marching + secant (endosurf.py:344-449); n_steps is always 128 there. Fixed shape on device."""
+        rays = self._rays32(rays)
+        weff, packed = self._weights()
+        with torch.no_grad():
+            return self.engine.ray_marching(rays, weff.detach(), packed, self.use_deform, int(n_steps[0]), n_secant_steps, tau)
+
+    def surface_neighbour_error(self, rays, mask, iter_step=0, neighbour_rad=0.05, u_neigh=None):
+        """reference surface_neighbour_error (endosurf.py:319-342), evaluated at fixed shape (all rays, masked mean)
+        so that no host synchronisation is needed; returns a 0-d tensor (0 when no ray is valid)."""
+        rays = self._rays32(rays)
+        N = rays.shape[0]
+        rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+        rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
+        with torch.no_grad():
+            d_i = self.ray_marching(rays)
+            valid = (torch.isfinite(d_i) & (d_i != 0) & (mask == 1))[:, 0]
+            d_safe = torch.where(valid[:, None], d_i, torch.zeros_like(d_i))
+            p_surf = rays_o + d_safe * rays_d_z
+            u = u_neigh if u_neigh is not None else torch.rand(N, 3, device=self.device)
+            p_neig = p_surf + (u.to(torch.float32) - 0.5) * neighbour_rad
+            pp = torch.cat([p_surf, p_neig], 0).contiguous()
+            tt = torch.cat([time, time], 0).contiguous()
+        _, g = self._point_eval(pp, tt)
+        normal = g / (torch.linalg.norm(g, ord=2, dim=-1, keepdim=True) + 1e-10)
+        diff = (normal[:N] - normal[N:]).abs() * valid[:, None].to(self.dtype)
+        n_valid = valid.sum()
+        return diff.sum() / torch.clamp(n_valid * 3, min=1).to(self.dtype)
+
+    # ---- offline helpers (reference endosurf.py:490-521) -----------------------------------------------------------------
+    def sdf_observed(self, pts, t):
+        """get_sdf_from_observed_space (endosurf.py:570-579) for [M,3] points and [M] / scalar time, no grad."""
+        weff, packed = self._weights()
+        x = pts.detach().to(torch.float32).contiguous()
+        tt = t.detach().to(torch.float32).reshape(-1).contiguous()
+        with torch.no_grad():
+            return self.engine.query_sdf(self.engine.points(x=x, t=tt), weff.detach(), packed, self.use_deform).view(-1, 1)

@@ -1,0 +1,64 @@
+"""End-to-end GPU parity of the drop-in renderer against the reference's golden outputs / the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import renderer_for_case
+from oracle_util import CASES, T, load_case, oracle_for
+
+pytestmark = pytest.mark.gpu
+
+
+def err(a, b, q=1.0):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return float(d.max() if q >= 1.0 else np.quantile(d, q))
+
+
+def budget(c, key, k=3.0, floor=2e-6, q=1.0):
+    """k x the reference's own fp32 error against its fp64 run on this output (the honest fp32 tolerance)."""
+    return k * err(c[f"render/{key}"], c[f"render64/{key}"], q) + floor
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_render_rays_forward(name):
+    c = load_case(name)
+    r = renderer_for_case(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    u = torch.from_numpy(c["u_perturb"]).cuda() if "u_perturb" in c else None
+    r.eval()
+    with torch.no_grad():
+        ret = r(rays, iter_step=int(c["meta/iter_step"]), perturb_overwrite=u is not None, u_perturb=u)
+    torch.cuda.synchronize()
+    ref_keys = ["color_map", "depth_map", "gradients_o", "gradient_o_error", "weights", "weight_max", "cdf", "s_val"]
+    assert sorted(ret.keys()) == sorted(ref_keys)
+    for k in ref_keys:
+        assert tuple(ret[k].shape) == c[f"render/{k}"].shape, k
+    # compared with the reference's fp64 run; allowed error = 3x the reference's own fp32-vs-fp64 error (+ floor)
+    assert err(ret["color_map"], c["render64/color_map"]) < budget(c, "color_map", floor=5e-6)
+    assert err(ret["depth_map"], c["render64/depth_map"]) < budget(c, "depth_map", floor=1e-5)
+    assert err(ret["weight_max"], c["render64/weight_max"]) < budget(c, "weight_max", floor=2e-5)
+    assert err(ret["s_val"], c["render64/s_val"]) < 1e-7
+    e64 = float(c["render64/gradient_o_error"])
+    assert abs(float(ret["gradient_o_error"]) - e64) < 3 * abs(float(c["render/gradient_o_error"]) - e64) + 1e-5 * max(1.0, e64)
+    for k in ("weights", "cdf"):
+        assert err(ret[k], c[f"render64/{k}"], 0.999) < budget(c, k, q=0.999, floor=1e-5), k
+        assert err(ret[k], c[f"render64/{k}"]) < 2e-2, k
+    assert err(ret["gradients_o"], c["render64/gradients_o"], 0.99) < budget(c, "gradients_o", q=0.99, floor=2e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_aux_forward(name):
+    c = load_case(name)
+    r = renderer_for_case(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    with torch.no_grad():
+        se, ae, inside = r.errorondepth(rays, torch.from_numpy(c["target/depth"]).cuda(), torch.from_numpy(c["target/mask"]).cuda())
+        d_i = r.ray_marching(rays)
+        sn = r.surface_neighbour_error(rays, torch.from_numpy(c["target/mask"]).cuda(), neighbour_rad=0.1,
+                                       u_neigh=torch.from_numpy(c["u_neigh"]).cuda())
+    assert abs(float(se) - float(c["eod64/sdf_error"])) < 3 * abs(float(c["eod/sdf_error"]) - float(c["eod64/sdf_error"])) + 5e-6
+    assert abs(float(ae) - float(c["eod64/angle_error"])) < 3 * abs(float(c["eod/angle_error"]) - float(c["eod64/angle_error"])) + 5e-6
+    assert np.array_equal(inside.cpu().numpy(), c["eod/inside"])
+    assert np.array_equal(np.isinf(d_i.cpu().numpy()), np.isinf(c["march64/d_i"]))
+    assert abs(float(sn) - float(c["sn64/value"])) < 3 * abs(float(c["sn/value"]) - float(c["sn64/value"])) + 5e-5
