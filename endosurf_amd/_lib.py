@@ -61,6 +61,7 @@ PROTOTYPES = {
     "es_point_workspace_floats": (C.c_int64, [_I, _I]),
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
+    "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _P, _P, _P, _P]),
 }
 
 PF_DEFORM, PF_COLOR, PF_SAVE = 1, 2, 4

@@ -13,6 +13,9 @@ int weightnorm_backward(const float* params, const float* dweff, float* dparams,
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
+int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
+                          const float* d_go, const float* d_rgb, hipStream_t st);
+int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, hipStream_t st);
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
 int upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
@@ -167,6 +170,16 @@ int es_point_forward(const es_points* pts, const float* packed, const float* wef
     ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
     ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode == 1 || pts->dirs, "colour evaluation needs view directions");
     return point_forward(to_src(pts), packed, weff, ws, flags, (hipStream_t)stream);
+}
+
+int es_point_backward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
+                      const float* d_go, const float* d_rgb, float* dweff, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(flags & ES_PF_SAVE, "es_point_backward needs a workspace produced with ES_PF_SAVE");
+    ES_REQUIRE(packed && weff && dweff && (pts->M == 0 || (ws && d_sdf && d_go)), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
+    if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
+    return point_wgrad(pts->M, ws, flags, d_sdf, dweff, (hipStream_t)stream);
 }
 
 }  // extern "C"

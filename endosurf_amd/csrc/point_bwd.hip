@@ -1,0 +1,470 @@
+// K6: hand-written backward of the fused point evaluation (the reference gets it from autograd with
+// create_graph=True double-backward, endosurf.py:598, 616, 640-656).  Given adjoints of (sdf, g_o, rgb) per point:
+//   color_bwd   reverse sweep through ColorNetwork -> adjoints of its pre-activations (for the weight-gradient GEMMs)
+//               and of its inputs: x_c (via enc10), g_c, d_c -> J (via normalize(J d)), feat
+//   sdf_bwd     (i) forward tangent sweep along gbar_c: the adjoint of the reverse-mode input gradient g_c is a
+//               forward-mode directional derivative; yields tau_l and the second-order terms 100(1-phi')rho_l pi_l
+//               (softplus''); (ii) ordinary reverse sweep of the value pass seeded with [sdfbar, featbar]
+//   deform_bwd  reverse sweep on 4 rows per point (value row seeded with xbar_c, tangent rows with Jbar); ReLU'' = 0
+// Weight gradients are formed afterwards by wgrad.hip from the streamed (input, adjoint) pairs.
+#include "chain_common.h"
+#include "encode.h"
+#include "launch.h"
+#include "tabs.h"
+#include "workspace.h"
+
+namespace es {
+
+struct BwdArgs {
+    PointSrc src;
+    Tabs tb;
+    const float4* packed;
+    const float* weff;
+    float* ws;
+    WsLayout L;
+    int flags;
+    const float* d_sdf;   // [M]
+    const float* d_go;    // [M][3]
+    const float* d_rgb;   // [M][3] (colour only)
+};
+__device__ __forceinline__ float* wsb(const BwdArgs& a, int buf) { return a.ws + a.L.off[buf]; }
+
+// d enc/dx contraction: sum_k adj[k] * d enc_k / d x_j for a 3-D encoding with L frequencies starting at row kbase
+template <int L>
+__device__ __forceinline__ float enc3_adjoint(const float* At, int kbase, int j, int row, float x) {
+    float g = At[swz(kbase + j, row)];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float f = (float)(1 << i);
+        float s, co;
+        sincosf(x * f, &s, &co);
+        g += f * (At[swz(kbase + enc_index(3, i, 0, j), row)] * co - At[swz(kbase + enc_index(3, i, 1, j), row)] * s);
+    }
+    return g;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* y8 = scr;           // [3][64]
+    float* px = scr + 192;     // [3][64] x_c
+    float* pd = scr + 384;     // [3][64] d_c
+    float* tx = scr + 576;     // [3][64]
+    float* td = scr + 768;     // [3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TM;
+    const size_t grow0 = (size_t)row0;
+    const bool deform = a.flags & PF_DEFORM;
+    const size_t Mp = (size_t)a.L.Mp;
+    float dray[3] = {0.f, 0.f, 1.f};
+
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        const bool valid = row0 + tid < a.src.M;
+        float x[3], t;
+        load_point(a.src, row0 + tid, x, t, dray);
+        const float* rgb = wsb(a, WS_RGB) + gp * 3;
+        float* Y8 = wsb(a, WS_C_Y8) + gp * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float c = rgb[i];
+            const float y = valid ? a.d_rgb[3 * (size_t)(row0 + tid) + i] * c * (1.f - c) : 0.f;   // sigmoid'
+            y8[i * 64 + tid] = y; Y8[i] = y;
+        }
+        Y8[3] = 0.f;
+        const float* xc = wsb(a, WS_XC) + gp * 3;
+        px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
+        float v0 = dray[0], v1 = dray[1], v2 = dray[2];
+        if (deform) {
+            const float* J = wsb(a, WS_J) + gp * 9;
+            v0 = J[0] * dray[0] + J[1] * dray[1] + J[2] * dray[2];
+            v1 = J[3] * dray[0] + J[4] * dray[1] + J[5] * dray[2];
+            v2 = J[6] * dray[0] + J[7] * dray[1] + J[8] * dray[2];
+        }
+        const float inv = 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
+        pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
+    }
+    __syncthreads();
+    const float* CH = wsb(a, WS_C_H);
+    float* CY = wsb(a, WS_C_Y);
+    {   // ybar_7 = relu'(y_7) * (U8^T ybar_8)
+        const float* U8 = a.weff + a.tb.woff[NET_C * LAYERS + 8];
+        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+            const float u0 = U8[col], u1 = U8[256 + col], u2 = U8[512 + col];
+            float h[4], v[4];
+            g_load_quad(CH + (size_t)7 * Mp * 256, grow0, 256, row, col, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float hb = y8[row + i] * u0 + y8[64 + row + i] * u1 + y8[128 + row + i] * u2;
+                v[i] = h[i] > 0.f ? hb : 0.f;
+            }
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(CY + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+        });
+    }
+    __syncthreads();
+    auto epi = [&](f32x16(&acc)[2][2], int l) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
+        const float* Hl = CH + (size_t)(l - 1) * Mp * 256;
+        float* Yl = CY + (size_t)(l - 1) * Mp * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float h[4];
+            g_load_quad(Hl, grow0, 256, row, col, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = h[i] > 0.f ? v[i] : 0.f;
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(Yl, grow0, 256, row, col, v);
+        });
+    };
+    float* FB = wsb(a, WS_FEATBAR);
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        if (l == 4) {   // skip layer: adjoint also flows to the network input [small(93) | feat(256)]
+            {
+                f32x16 accF[2][2];
+                acc_zero(accF);
+                gemm_seg<32, 2, 2>(accF, mainT, a.packed + a.tb.segoff[CR4F], 0, 2 * wave, lane);
+                for_quads(accF, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) { g_store_quad(FB, grow0, 256, row, col, v); });
+            }
+            {
+                f32x16 accS[2][1];
+                acc_zero(accS);
+                gemm_seg<32, 2, 1>(accS, mainT, a.packed + a.tb.segoff[CR4S], 0, wave, lane);
+                for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+            }
+        }
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l < 4 ? CR1 + (l - 1) : (l == 4 ? (int)CR4H : CR5 + (l - 5));
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
+        __syncthreads();
+        epi(acc, l);
+        __syncthreads();
+    }
+    {   // layer 0: adjoint of the network input
+        f32x16 accF[2][2];
+        acc_zero(accF);
+        gemm_seg<32, 2, 2>(accF, mainT, a.packed + a.tb.segoff[CR0F], 0, 2 * wave, lane);
+        for_quads(accF, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float p[4];
+            g_load_quad(FB, grow0, 256, row, col, p);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += p[i];
+            g_store_quad(FB, grow0, 256, row, col, v);
+        });
+        f32x16 accS[2][1];
+        acc_zero(accS);
+        gemm_seg<32, 2, 1>(accS, mainT, a.packed + a.tb.segoff[CR0S], 0, wave, lane);
+        for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int j = tid >> 6, row = tid & 63;
+        tx[j * 64 + row] = enc3_adjoint<10>(aux, 0, j, row, px[j * 64 + row]);
+        td[j * 64 + row] = enc3_adjoint<4>(aux, 66, j, row, pd[j * 64 + row]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        float* xb = wsb(a, WS_XCBAR_C) + gp * 3;
+        float* gb = wsb(a, WS_GCBAR_C) + gp * 3;
+        float* Jb = wsb(a, WS_JBAR_C) + gp * 9;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xb[j] = tx[j * 64 + tid]; gb[j] = aux[swz(63 + j, tid)]; }
+        if (deform) {   // d_c = v/(|v| + eps), v = J d  ->  vbar, Jbar = vbar d^T
+            const float* J = wsb(a, WS_J) + gp * 9;
+            float v[3], db[3] = {td[tid], td[64 + tid], td[128 + tid]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = J[3 * i] * dray[0] + J[3 * i + 1] * dray[1] + J[3 * i + 2] * dray[2];
+            const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const float den = n + 1e-10f;
+            const float dot = v[0] * db[0] + v[1] * db[1] + v[2] * db[2];
+            const float k2 = n > 0.f ? dot / (n * den * den) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float vb = db[i] / den - v[i] * k2;
+                Jb[3 * i] = vb * dray[0]; Jb[3 * i + 1] = vb * dray[1]; Jb[3 * i + 2] = vb * dray[2];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Jb[i] = 0.f;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* px = scr;           // [3][64] x_c
+    float* gb = scr + 192;     // [3][64] gbar_c
+    float* sb = scr + 384;     // [64] sdfbar
+    float* tx = scr + 448;     // [3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * TM;
+    const size_t grow0 = (size_t)row0;
+    const bool deform = a.flags & PF_DEFORM, color = a.flags & PF_COLOR;
+    const size_t Mp = (size_t)a.L.Mp;
+
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        const bool valid = row0 + tid < a.src.M;
+        float go[3] = {0.f, 0.f, 0.f};
+        if (valid) { go[0] = a.d_go[3 * (size_t)(row0 + tid)]; go[1] = a.d_go[3 * (size_t)(row0 + tid) + 1]; go[2] = a.d_go[3 * (size_t)(row0 + tid) + 2]; }
+        sb[tid] = valid ? a.d_sdf[row0 + tid] : 0.f;
+        const float* xc = wsb(a, WS_XC) + gp * 3;
+        px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
+        const float* gc = wsb(a, WS_GC) + gp * 3;
+        float Jm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        if (deform) {
+            const float* J = wsb(a, WS_J) + gp * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Jm[i] = J[i];
+        }
+        float* Jb = wsb(a, WS_JBAR) + gp * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float g = Jm[3 * i] * go[0] + Jm[3 * i + 1] * go[1] + Jm[3 * i + 2] * go[2];       // g_o = J^T g_c  ->  gbar_c = J gbar_o
+            if (color) g += wsb(a, WS_GCBAR_C)[gp * 3 + i];
+            gb[i * 64 + tid] = g;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Jb[3 * i + k] = (color ? wsb(a, WS_JBAR_C)[gp * 9 + 3 * i + k] : 0.f) + gc[i] * go[k];
+        }
+    }
+    __syncthreads();
+    {   // tau_0 = (d enc6 / d x_c) gbar_c
+        const int row = tid & 63, part = tid >> 6;
+        for (int item = part; item < 18; item += 4) {
+            const int c = item % 3, i = item / 3;
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(px[c * 64 + row] * f, &s, &co);
+            const float g = gb[c * 64 + row];
+            aux[swz(enc_index(3, i, 0, c), row)] = f * co * g;
+            aux[swz(enc_index(3, i, 1, c), row)] = -f * s * g;
+        }
+        if (part == 3) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) aux[swz(c, row)] = gb[c * 64 + row];
+            aux[swz(39, row)] = 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        float* T0 = wsb(a, WS_S_TAU0);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 40; k += 4) T0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+    }
+    const float* SACT = wsb(a, WS_S_ACT);
+    const float* RHO = wsb(a, WS_S_RHO);
+    float* TAU = wsb(a, WS_S_TAU);
+    float* ZB = wsb(a, WS_S_ZB);
+    // ---- (i) forward tangent sweep ----
+    auto epi_t = [&](f32x16(&acc)[2][2], int l) {   // acc = pi_l
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4], r[4], z2[4];
+            g_load_quad(SACT + (size_t)l * Mp * 256, grow0, 256, row, col, s);
+            g_load_quad(RHO + (size_t)l * Mp * 256, grow0, 256, row, col, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dphi = softplus100_grad_from_s(s[i]);
+                z2[i] = 100.f * (1.f - dphi) * r[i] * v[i];      // softplus'' / softplus' = 100 (1 - softplus')
+                v[i] = dphi * v[i];                               // tau_{l+1}
+            }
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(TAU + (size_t)l * Mp * 256, grow0, 256, row, col, v);
+            g_store_quad(ZB + (size_t)l * Mp * 256, grow0, 256, row, col, z2);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
+        epi_t(acc, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
+        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
+        __syncthreads();
+        epi_t(acc, l);
+        __syncthreads();
+    }
+    // ---- (ii) reverse sweep of the value pass, seeded with zbar_8 = [sdfbar | featbar] ----
+    auto epi_b = [&](f32x16(&acc)[2][2], int l) {   // acc = sbar_l (adjoint of s_l); zbar_{l-1} = phi'(z_{l-1}) sbar_l + second-order
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4], z2[4];
+            g_load_quad(SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, s);
+            g_load_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, z2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        if (color) {
+            load_tile_256(mainT, wsb(a, WS_FEATBAR), grow0, 256, tid);
+            __syncthreads();
+            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[SR8F], 0, 2 * wave, lane);
+            __syncthreads();
+        }
+        const float* w8 = a.weff + a.tb.woff[NET_S * LAYERS + 8];
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            const float w = w8[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += sb[row + i] * w;
+            float s[4], z2[4];
+            g_load_quad(SACT + (size_t)7 * Mp * 256, grow0, 256, row, col, s);
+            g_load_quad(ZB + (size_t)7 * Mp * 256, grow0, 256, row, col, z2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(ZB + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+        });
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
+        f32x16 accA[1][1];
+        if (l == 4) {
+            acc_zero(accA);
+            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);
+        }
+        __syncthreads();
+        epi_b(acc, l);
+        if (l == 4)
+            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+        __syncthreads();
+    }
+    {
+        f32x16 accA[1][1];
+        acc_zero(accA);
+        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
+        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int j = tid >> 6, row = tid & 63;
+        const float x = px[j * 64 + row];
+        float g = enc3_adjoint<6>(aux, 0, j, row, x);
+        // second-order encoding term: sum_k adj_eps[k] * d2 enc_k / dx_j^2 * gbar_c[j]
+        const float* AE = wsb(a, WS_S_ADJEPS) + (grow0 + row) * 64;
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(x * f, &s, &co);
+            h -= f * f * (AE[enc_index(3, i, 0, j)] * s + AE[enc_index(3, i, 1, j)] * co);
+        }
+        tx[j * 64 + row] = g + h * gb[j * 64 + row];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const size_t gp = grow0 + tid;
+        float* xb = wsb(a, WS_XCBAR) + gp * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xb[j] = tx[j * 64 + tid] + (color ? wsb(a, WS_XCBAR_C)[gp * 3 + j] : 0.f);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_deform_bwd(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;
+    float* scr = aux + AUX_FLOATS;
+    float* a8 = scr;   // [3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt0 = blockIdx.x * 16;
+    const size_t grow0 = (size_t)pt0 * 4;
+    const size_t rows4 = (size_t)a.L.Mp * 4;
+
+    if (tid < 64) {
+        const int p = tid >> 2, c = tid & 3;
+        const size_t gp = (size_t)(pt0 + p);
+        float* A8 = wsb(a, WS_D_A8) + (grow0 + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float v = c == 0 ? wsb(a, WS_XCBAR)[gp * 3 + i] : wsb(a, WS_JBAR)[gp * 9 + 3 * i + (c - 1)];
+            a8[i * 64 + tid] = v; A8[i] = v;
+        }
+        A8[3] = 0.f;
+    }
+    __syncthreads();
+    const float* U = wsb(a, WS_D_U);
+    float* DA = wsb(a, WS_D_A);
+    {   // abar_7 = mask_7 * (W8^T abar_8)
+        const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
+        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+            const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
+            const bool m = U[(size_t)7 * rows4 * 256 + (grow0 + row) * 256 + col] > 0.f;   // value row of this point
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m ? a8[row + i] * w0 + a8[64 + row + i] * w1 + a8[128 + row + i] * w2 : 0.f;
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(DA + (size_t)7 * rows4 * 256, grow0, 256, row, col, v);
+        });
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
+        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR1 + (l - 1)], 0, 2 * wave, lane);
+        __syncthreads();
+        const float* Ul = U + (size_t)(l - 1) * rows4 * 256;
+        float* Al = DA + (size_t)(l - 1) * rows4 * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            // layer 3 has 204 outputs: the skip's encoding part (cols >= 204) carries no parameter gradient
+            const bool m = (l == 4 && col >= 204) ? false : Ul[(grow0 + row) * 256 + col] > 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m ? v[i] : 0.f;
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(Al, grow0, 256, row, col, v);
+        });
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
+                          const float* d_go, const float* d_rgb, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (int e = allow_big_lds(k_color_bwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_bwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_bwd, LDS_BYTES)) return e;
+        attr_done = true;
+    }
+    if (src.M <= 0) return ST_OK;
+    BwdArgs a;
+    a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
+    a.L = ws_layout(src.M, flags); a.flags = flags; a.d_sdf = d_sdf; a.d_go = d_go; a.d_rgb = d_rgb;
+    const int Mp = a.L.Mp;
+    if (flags & PF_COLOR) hipLaunchKernelGGL(k_color_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
+    if (flags & PF_DEFORM) hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a);
+    return hip_last("point_backward_chains");
+}
+
+}  // namespace es

@@ -215,3 +215,19 @@ def _point_forward(self, pts, weff, packed, flags: int) -> PointCtx:
 
 
 Engine.point_forward = _point_forward
+
+
+def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None):
+    """Adjoints of (sdf [M,1], g_o [M,3], rgb [M,3]) -> gradient w.r.t. the effective-weight buffer."""
+    M = ctx.M
+    z = lambda g, w: (g.detach().to(torch.float32).contiguous() if g is not None else self.zeros(M, w))
+    d_sdf, d_go = z(d_sdf, 1), z(d_go, 3)
+    color = bool(ctx.flags & _lib.PF_COLOR)
+    d_rgb = z(d_rgb, 3) if color else None
+    dweff = self.zeros(self.n_weff)
+    check(self.lib.es_point_backward(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ptr(d_sdf), ptr(d_go),
+                                     ptr(d_rgb) if color else None, ptr(dweff), stream_ptr()), "es_point_backward")
+    return dweff
+
+
+Engine.point_backward = _point_backward
