@@ -1,0 +1,102 @@
+"""Thin training-step counterpart of the reference's EndoSurfTrainer (src/trainer/trainer_endosurf.py:94-203): the loss
+arithmetic, Adam and the warm-up + cosine LR schedule around the drop-in renderer.  Host orchestration only (PyTorch-ROCm);
+no logging / host synchronisation inside a step (the reference's 12 ``.item()`` calls per step live in its logger)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+LOSS_WEIGHTS = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)   # base_pull.yml:23-29
+
+
+def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
+                 u_perturb=None, u_neigh=None):
+    """compute_loss (trainer_endosurf.py:106-162) without the TensorBoard calls. Returns (total, terms, render dict)."""
+    rays, color_gt, depth_gt = batch["rays"], batch["color"], batch["depth"]
+    mask_gt, cmask = batch["mask"], batch["color_mask"]
+    ret = renderer(rays, iter_step=iter_step, u_perturb=u_perturb)
+    color_error = (ret["color_map"] - color_gt) * cmask
+    color_loss = color_error.abs().sum() / (cmask.sum() + 1e-10)
+    sdf_loss, angle_loss, valid = renderer.errorondepth(rays, d_gt=depth_gt, mask=mask_gt, iter_step=iter_step)
+    depth_error = (ret["depth_map"] - depth_gt) * valid * mask_gt
+    depth_loss = depth_error.abs().sum() / ((valid * mask_gt).sum() + 1e-10)
+    eik = ret["gradient_o_error"]
+    sn = renderer.surface_neighbour_error(rays=rays, mask=mask_gt, iter_step=iter_step, neighbour_rad=surf_neig_rad, u_neigh=u_neigh)
+    total = (color_loss * weights["color"] + depth_loss * weights["depth"] + sdf_loss * weights["sdf"]
+             + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
+    terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
+    return total, terms, ret
+
+
+def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
+    """update_learning_rate (trainer_endosurf.py:183-203)."""
+    if it < warm_up_end:
+        return it / warm_up_end
+    prog = (it - warm_up_end) / (n_iter - warm_up_end)
+    return (math.cos(math.pi * prog) + 1.0) * 0.5 * (1 - alpha) + alpha
+
+
+def cal_psnr(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """cal_psnr (src/trainer/utils.py:340-353), kept on device (no host sync)."""
+    if mask.dim() == a.dim() - 1:
+        mask = mask[..., None]
+    mask_sum = mask.sum() + 1e-10
+    return 20.0 * torch.log10(1.0 / torch.sqrt(((a - b) ** 2 * mask).sum() / (mask_sum * 3.0)))
+
+
+class SyntheticScene:
+    """Build-owned synthetic stand-in for Dataset.get_train_batch_data_by_index (dataset.py:117-161): pinhole camera
+    640x512, f = 800 px at o = (0,0,-1.5) looking down +z, one time value per batch; targets are uniform colours,
+    depth 1.2 + 0.2 U, masks = 1 (SURVEY 8d / BASELINE.md 3). Everything is generated on the device."""
+
+    def __init__(self, device, seed: int = 0, jitter: float = 0.01):
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.jitter = jitter
+
+    def batch(self, n_rays: int) -> Dict[str, torch.Tensor]:
+        g, dev = self.gen, self.device
+        u = torch.rand(n_rays, generator=g, device=dev) * 639.0
+        v = torch.rand(n_rays, generator=g, device=dev) * 511.0
+        d = torch.stack([(u - 319.5) / 800.0, (v - 255.5) / 800.0, torch.ones_like(u)], -1)
+        d = d / d.norm(dim=-1, keepdim=True)
+        o = torch.tensor([0.0, 0.0, -1.5], device=dev)[None] + self.jitter * torch.randn(n_rays, 3, generator=g, device=dev)
+        t = torch.rand(1, generator=g, device=dev).expand(n_rays, 1)
+        rays = torch.cat([o, d, torch.zeros(n_rays, 2, device=dev), t], -1).contiguous()
+        return dict(rays=rays, color=torch.rand(n_rays, 3, generator=g, device=dev),
+                    depth=1.2 + 0.2 * torch.rand(n_rays, 1, generator=g, device=dev),
+                    mask=torch.ones(n_rays, 1, device=dev), color_mask=torch.ones(n_rays, 1, device=dev))
+
+
+class Trainer:
+    """zero_grad -> compute_loss -> backward -> (data-parallel gradient all-reduce) -> Adam  (train_step, trainer_endosurf.py:94-104)."""
+
+    def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
+                 loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False):
+        self.renderer = renderer
+        groups = renderer.get_train_params()
+        self.params = [p for k in groups for p in groups[k]]
+        self.optimizer = torch.optim.Adam(params=self.params, lr=lr)     # defaults like the reference (trainer_endosurf.py:70)
+        self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
+        self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
+        self.data_parallel = data_parallel
+
+    def update_learning_rate(self, global_step: int):
+        lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+        return lr
+
+    def train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, terms, ret = compute_loss(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
+        loss.backward()
+        if self.data_parallel:
+            from .parallel import allreduce_gradients
+            allreduce_gradients(self.params)
+        self.optimizer.step()
+        return loss.detach(), terms, ret
