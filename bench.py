@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training rays/s of EndoSurf's renderer hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload = BASELINE config 2: base_pull.yml networks, 1024 rays x (32 coarse + 32 importance) samples per GPU, one FULL
+training step per "step": render (hierarchical sampling + fused MLP stack + compositing) + errorondepth +
+surface_neighbour_error (128-step ray marching + 8 secant steps) + loss + backward + Adam, on synthetic rays/targets
+already resident in HBM, random-init weights (reference initialisation), fp32 throughout.  Weak scaling: every rank
+draws its own 1024-ray batch, one RCCL all-reduce of the 6.6 MB gradient bucket per step.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+RENDER_CFG = dict(net_chunk=80000, anneal_end=50000, n_samples=32, n_importance=32, important_begin_iter=0, up_sample_steps=4,
+                  perturb=True)
+NET_CFG = dict(
+    bound=1.0, use_deform=True,
+    deform_network=dict(enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=6),
+                        enc_time_cfg=dict(enc_type="frequency", input_dim=1, multires=6), n_layers=9, hidden_dim=256, skips=[4], out_dim=3),
+    sdf_network=dict(enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=6), n_layers=9, hidden_dim=256, skips=[4], out_dim=257,
+                     geometric_init=True, geometric_init_bias=0.8),
+    color_network=dict(enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=10),
+                       enc_dir_cfg=dict(enc_type="frequency", input_dim=3, multires=4), n_layers=9, hidden_dim=256, skips=[4],
+                       feat_dim=256, out_dim=3),
+    deviation_network=dict(init_val=0.3))
+N_RAYS = 1024
+# per-point MACs of the three MLPs (SURVEY 8 / BASELINE.md 2)
+MAC_D, MAC_S, MAC_C = 459520, 544512, 638208
+
+
+def flops_per_ray_forward(S_c=32, S_i=32, steps=4):
+    f_up = 2 * (S_c + S_i * (steps - 1) / steps) * (MAC_D + MAC_S)
+    f_core = 2 * (S_c + S_i) * (4 * MAC_D + 2 * MAC_S + MAC_C)
+    return f_up, f_core
+
+
+def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=20):
+    """The oracle (CPU restatement of the reference op sequence, torch-CPU fp32 + autograd) timed on this box's host cores
+    on a bounded sample of the same workload: full training steps at ``n_rays`` rays."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import numpy as np
+    import weightgen
+    from oracle import endosurf_oracle as O
+    state = weightgen.make_state(0, "init", True)
+    params = {k: torch.tensor(v, requires_grad=True) for k, v in state.items()}
+    R = O.OracleRenderer(O.OracleNet(params, True), RENDER_CFG)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4)
+    rays = torch.from_numpy(weightgen.make_rays(1, n_rays))
+    tg = {k: torch.from_numpy(v) for k, v in weightgen.make_targets(2, n_rays).items()}
+    batch = dict(rays=rays, **tg)
+    rng = np.random.default_rng(0)
+
+    def step():
+        opt.zero_grad()
+        u = torch.from_numpy(rng.uniform(size=(n_rays, 1)).astype(np.float32))
+        un = torch.from_numpy(rng.uniform(size=(n_rays, 3)).astype(np.float32))
+        loss, _, _ = O.train_loss(R, batch, 1, u, un)
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    it = 0
+    while it < max_iters and (time.perf_counter() - t0 < min_seconds or it < 2):
+        step()
+        it += 1
+    dt = (time.perf_counter() - t0) / it
+    return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{it} full training steps of the CPU oracle at {n_rays} rays x 64 samples (torch-CPU fp32, autograd), {dt:.2f} s/step")
+
+
+# algorithmic MACs per point of each kernel (forward core = 4D + 2S + C, backward chains the same again,
+# weight gradients the same again; the SDF query = D + S)
+KERNEL_MACS = {"k_query_sdf": MAC_D + MAC_S, "k_deform_fwd": 4 * MAC_D, "k_sdf_fwd": 2 * MAC_S, "k_color_fwd": MAC_C,
+               "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_bwd": 4 * MAC_D, "k_wgrad[deform]": 4 * MAC_D,
+               "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}
+
+
+def kernel_timing(eng, step, first_step, n_steps):
+    """A few extra steps of the SAME workload with the library's HIP-event timers on (events recorded on the launch stream
+    around every chain / weight-gradient kernel).  Kept out of the headline region so the events do not perturb ``value``."""
+    eng.timing_enable(True)
+    eng.timing_drain()
+    for i in range(n_steps):
+        step(first_step + i)
+    torch.cuda.synchronize()
+    rec = eng.timing_drain()
+    eng.timing_enable(False)
+    groups = {}
+    for name, rows, ms in rec:
+        g = groups.setdefault((name, rows), [0.0, 0])
+        g[0] += ms
+        g[1] += 1
+    per_step = {}
+    for (name, rows), (tot, cnt) in groups.items():
+        per_step[name] = per_step.get(name, 0.0) + tot / n_steps
+    out = {"per_step_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+    cand = [(tot, name, rows, cnt) for (name, rows), (tot, cnt) in groups.items() if name in KERNEL_MACS]
+    if cand:
+        tot, name, rows, cnt = max(cand)
+        out["dominant"] = (f"{name} ({rows} points per launch)", tot / cnt, cnt)
+        out["dominant_flops_per_launch"] = 2.0 * KERNEL_MACS[name] * rows
+        out["all"] = [dict(kernel=n, points=r, launches=c, avg_ms=round(t / c, 4),
+                           tflops=round(2.0 * KERNEL_MACS[n] * r / (t / c * 1e-3) / 1e12, 2)) for t, n, r, c in sorted(cand, reverse=True)]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=N_RAYS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    args = ap.parse_args()
+
+    from endosurf_amd import EndoSurfRenderer, parallel
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+    rank, world, local = parallel.init_distributed("nccl" if args.gpus > 1 else None)
+    assert world == max(1, args.gpus) or args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)
+    renderer = EndoSurfRenderer(dict(RENDER_CFG), NET_CFG, device=dev)
+    trainer = Trainer(renderer, data_parallel=world > 1)
+    parallel.broadcast_parameters(trainer.params)
+    scene = SyntheticScene(dev, seed=1234 + rank)
+    batches = [scene.batch(args.rays) for _ in range(4)]      # resident in HBM before the timed region
+    eng = renderer.engine
+
+    def step(i):
+        if args.mode == "train":
+            trainer.update_learning_rate(i + 1)
+            trainer.train_step(batches[i % len(batches)], i + 1)
+        else:
+            with torch.no_grad():
+                renderer(batches[i % len(batches)]["rays"], iter_step=i + 1)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    timing = kernel_timing(eng, step, args.warmup + args.steps, 3) if rank == 0 or world == 1 else {}
+    ms = dt / args.steps * 1e3
+    value = world * args.rays * args.steps / dt
+
+    if rank == 0:
+        f_up, f_core = flops_per_ray_forward()
+        # dominant kernel: the deformation-network forward (value + 3 tangents): 4 * MAC_D MACs per point, P = rays * 64 points
+        roof = None
+        if timing.get("dominant"):
+            name, avg_ms, count = timing["dominant"]
+            flops = timing["dominant_flops_per_launch"]
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=None, kernel=name,
+                        avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
+        out = dict(metric="training rays/sec (1024 rays x 64 samples)" if args.mode == "train" else "forward rays/sec (1024 rays x 64 samples)",
+                   value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="base_pull.yml nets, %d rays x (32+32) samples per GPU, %s" % (
+                       args.rays, "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam"
+                       if args.mode == "train" else "renderer forward only"),
+                       rays_per_gpu=args.rays, samples_per_ray=64, parallelism=f"dp{world}", weights="reference init, torch.manual_seed(0)",
+                       algorithmic_gflop_per_ray=dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9,
+                                                      train_step=(f_up + 3 * f_core + 2 * 128 * (MAC_D + MAC_S)) / 1e9)),
+                   roofline=roof, kernel_ms_per_step=timing.get("per_step_ms"), kernel_launch_groups=timing.get("all"))
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,9 @@ PROTOTYPES = {
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "es_timing_enable": (_I, [_I]),
+    "es_timing_drain": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "es_kernel_name": (C.c_char_p, [_I]),
 }
 
 PF_DEFORM, PF_COLOR, PF_SAVE = 1, 2, 4

@@ -11,6 +11,7 @@
 #include "encode.h"
 #include "launch.h"
 #include "tabs.h"
+#include "timing.h"
 #include "workspace.h"
 
 namespace es {
@@ -461,9 +462,9 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags; a.d_sdf = d_sdf; a.d_go = d_go; a.d_rgb = d_rgb;
     const int Mp = a.L.Mp;
-    if (flags & PF_COLOR) hipLaunchKernelGGL(k_color_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
-    hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
-    if (flags & PF_DEFORM) hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a);
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, src.M, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_backward_chains");
 }
 

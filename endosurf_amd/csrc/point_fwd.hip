@@ -10,6 +10,7 @@
 #include "encode.h"
 #include "launch.h"
 #include "tabs.h"
+#include "timing.h"
 #include "workspace.h"
 
 namespace es {
@@ -406,9 +407,9 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags;
     const int Mp = a.L.Mp;
-    if (flags & PF_DEFORM) hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a);
-    hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
-    if (flags & PF_COLOR) hipLaunchKernelGGL(k_color_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a);
+    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
+    { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, src.M, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_forward");
 }
 

@@ -7,6 +7,7 @@
 #include "encode.h"
 #include "launch.h"
 #include "tabs.h"
+#include "timing.h"
 
 namespace es {
 
@@ -127,6 +128,7 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     if (src.M <= 0) return ST_OK;
     const Tabs tb = make_tabs();
     const dim3 grid((src.M + TM - 1) / TM), block(NTHREADS);
+    ScopedTimer tm(KID_QUERY, src.M, st);
     if (use_deform)
         hipLaunchKernelGGL(k_query_sdf<true>, grid, block, LDS_BYTES, st, src, tb, reinterpret_cast<const float4*>(packed), weff, sdf_out);
     else

@@ -11,6 +11,7 @@
 #include "chain_common.h"
 #include "launch.h"
 #include "tabs.h"
+#include "timing.h"
 #include "workspace.h"
 
 namespace es {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X
         for (int n = 0; n < N; ++n) atomicAdd(bias_out + n, bs[n]);
 }
 
-static int launch_group(WgProb* probs, int nprob, hipStream_t st) {
+static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipStream_t st) {
     if (nprob == 0) return ST_OK;
     ES_REQUIRE(nprob <= WG_MAX_PROBS, "too many weight-gradient problems in one group");
     // rows per task: aim at a few thousand wavefront tasks per launch
@@ -145,6 +146,7 @@ static int launch_group(WgProb* probs, int nprob, hipStream_t st) {
         a.p[i] = probs[i];
     }
     a.nprob = nprob; a.total_tasks = total; a.MC = MC;
+    ScopedTimer tm(kid, rows, st);
     hipLaunchKernelGGL(k_wgrad, dim3((total + 3) / 4), dim3(256), 0, st, a);
     return ST_OK;
 }
@@ -153,6 +155,7 @@ static void launch_small(const float* X, int ldx, const float* dA, int lda, int 
     int MC = (M + 255) / 256;
     MC = (MC + 63) / 64 * 64;
     if (MC < 64) MC = 64;
+    ScopedTimer tm(KID_WGRAD_SMALL, M, st);
     hipLaunchKernelGGL(k_wgrad_small, dim3((M + MC - 1) / MC), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride, MC);
 }
 
@@ -179,7 +182,7 @@ int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, h
         for (int l = 1; l <= 7; ++l)
             add(B(WS_D_U) + (size_t)(l - 1) * r256, 256, B(WS_D_A) + (size_t)l * r256, 256, R, 256, LAYER_N[NET_D][l], dW(NET_D, l), 256,
                 dB(NET_D, l), 4);
-        if (int e = launch_group(g, n, st)) return e;
+        if (int e = launch_group(g, n, KID_WGRAD_D, M, st)) return e;
         launch_small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 4, st);
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l)
@@ -197,7 +200,7 @@ int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, h
         }
         if (flags & PF_COLOR)   // feature rows 1..256 of the last layer
             add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mp, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
-        if (int e = launch_group(g, n, st)) return e;
+        if (int e = launch_group(g, n, KID_WGRAD_S, M, st)) return e;
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
         launch_small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, st);   // real rows only: d_sdf is [M]
         launch_small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, st);
@@ -214,7 +217,7 @@ int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, h
                 add(B(WS_FEAT), 256, B(WS_C_Y) + (size_t)4 * t256, 256, Mp, 256, 256, dW(NET_C, 4) + 349, K, nullptr, 1);
             }
         }
-        if (int e = launch_group(g, n, st)) return e;
+        if (int e = launch_group(g, n, KID_WGRAD_C, M, st)) return e;
         launch_small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mp, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1, st);
     }
     return hip_last("point_wgrad");

@@ -231,3 +231,23 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None):
 
 
 Engine.point_backward = _point_backward
+
+
+
+def _timing_enable(self, on: bool):
+    check(self.lib.es_timing_enable(int(on)), "es_timing_enable")
+
+
+def _timing_drain(self):
+    """[(kernel name, rows, ms)] of every launch recorded since the last drain."""
+    cap = 65536
+    kid = (C.c_int * cap)()
+    rows = (C.c_longlong * cap)()
+    ms = (C.c_float * cap)()
+    n = C.c_int()
+    check(self.lib.es_timing_drain(cap, kid, rows, ms, C.byref(n)), "es_timing_drain")
+    return [(self.lib.es_kernel_name(kid[i]).decode(), int(rows[i]), float(ms[i])) for i in range(n.value)]
+
+
+Engine.timing_enable = _timing_enable
+Engine.timing_drain = _timing_drain

@@ -89,14 +89,14 @@ def _render_scalar(ret, c, dt, dev):
 
 def _check_rows(rows, c, prefix64, prefix32, name):
     """HIP-vs-oracle64 error per tensor must stay within 3x the reference's own fp32-vs-fp64 gradient error
-    (computed from the golden norm summaries) or 2e-3, whichever is larger."""
+    (computed from the golden norm summaries) or 5e-3, whichever is larger."""
     bad = {}
     for k, (rel, nref, ngot) in rows.items():
         if nref < 1e-9:
             continue
         n64, n32 = float(c[f"{prefix64}/{k}/norm"]), float(c[f"{prefix32}/{k}/norm"])
         ref_noise = abs(n32 - n64) / (n64 + 1e-30)
-        tol = max(2e-3, 3 * ref_noise + 2e-2 * (ref_noise > 1e-3))
+        tol = max(5e-3, 3 * ref_noise + 2e-2 * (ref_noise > 1e-3))
         if abs(ngot - n64) / (n64 + 1e-30) > tol:
             bad[k] = (rel, ngot, n64, n32)
     assert not bad, (name, bad)
