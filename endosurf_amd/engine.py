@@ -209,7 +209,6 @@ class PointCtx:
 
 def _point_forward(self, pts, weff, packed, flags: int) -> PointCtx:
     ctx = PointCtx(self, pts, flags)
-    ctx.keep = (weff, packed)
     check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, stream_ptr()), "es_point_forward")
     return ctx
 

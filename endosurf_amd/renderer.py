@@ -9,6 +9,7 @@ every tensor op of the hot path runs inside the C-ABI library; there is no PyTor
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -189,25 +190,27 @@ class EndoSurfNet(nn.Module):
 # autograd glue
 # ---------------------------------------------------------------------------------------------------------------
 class _PackFn(torch.autograd.Function):
-    """(bias, weight_g, weight_v)* -> effective-weight buffer (+ packed MFMA fragments as a side product)."""
+    """(bias, weight_g, weight_v)* -> effective-weight buffer (+ packed MFMA fragments as a side product).
+
+    ctx never references the Function's own outputs (directly or through the model's cache): such a cycle runs through
+    C++ autograd nodes and is not collectable, which would leak the buffers every step."""
 
     @staticmethod
-    def forward(ctx, model: EndoSurfNet, eng: Engine, *plist):
+    def forward(ctx, model_ref, eng: Engine, *plist):
+        model = model_ref()
         weff, packed = eng.weightnorm_pack(model._flat, model.use_deform)
-        ctx.model, ctx.eng = model, eng
+        ctx.model_ref, ctx.eng, ctx.flat, ctx.use_deform = model_ref, eng, model._flat, model.use_deform
+        ctx.slots = [(model._layout[key][0], p.numel(), tuple(p.shape)) for key, p in model.ordered_params()]
         ctx.mark_non_differentiable(packed)
         return weff, packed
 
     @staticmethod
     def backward(ctx, dweff, _dpacked):
-        model, eng = ctx.model, ctx.eng
-        model._pack_cache = None
-        dflat = eng.weightnorm_backward(model._flat, dweff.contiguous(), model.use_deform)
-        grads = []
-        for key, p in model.ordered_params():
-            off, shape = model._layout[key]
-            grads.append(dflat[off:off + p.numel()].view(p.shape))
-        return (None, None, *grads)
+        model = ctx.model_ref()
+        if model is not None:
+            model._pack_cache = None
+        dflat = ctx.eng.weightnorm_backward(ctx.flat, dweff.contiguous(), ctx.use_deform)
+        return (None, None, *[dflat[off:off + n].view(shape) for off, n, shape in ctx.slots])
 
 
 class _PointEvalFn(torch.autograd.Function):
@@ -218,9 +221,9 @@ class _PointEvalFn(torch.autograd.Function):
         # grad mode is disabled inside Function.forward; the caller passes the save decision through ``flags``
         pctx = eng.point_forward(pts, weff, packed, flags)
         ctx.pctx, ctx.eng, ctx.weff, ctx.packed = pctx, eng, weff, packed
-        outs = [pctx.view("sdf"), pctx.view("go")]
+        outs = [pctx.view("sdf").clone(), pctx.view("go").clone()]     # own storage: outputs must not pin the workspace
         if flags & _lib.PF_COLOR:
-            outs.append(pctx.view("rgb"))
+            outs.append(pctx.view("rgb").clone())
         return tuple(outs)
 
     @staticmethod
@@ -229,11 +232,13 @@ class _PointEvalFn(torch.autograd.Function):
         if not (pctx.flags & _lib.PF_SAVE):
             raise RuntimeError("point evaluation was run without PF_SAVE; cannot backpropagate")
         dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, d_rgb)
+        ctx.pctx = None
         return dweff, None, None, None, None
 
 
 class _RenderFn(torch.autograd.Function):
-    """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing."""
+    """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing.
+    (ctx keeps inputs and the workspace only, never the outputs: see _PackFn.)"""
 
     @staticmethod
     def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int):
@@ -241,15 +246,15 @@ class _RenderFn(torch.autograd.Function):
         mid = eng.mid_z(z, sample_dist)
         pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S)
         pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR)
-        a = eng.composite_args(rays, z, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), variance.detach().reshape(1),
-                               sample_dist, cos_anneal)
+        var1 = variance.detach().reshape(1)
+        a = eng.composite_args(rays, z, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
         out = eng.composite_forward(a)
         eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
-        eik = (out["eik_acc"][0] / eik_den[0])
-        ctx.eng, ctx.pctx, ctx.a, ctx.out, ctx.eik_den = eng, pctx, a, out, eik_den
+        eik = out["eik_acc"][0] / eik_den[0]
+        ctx.eng, ctx.pctx, ctx.eik_den = eng, pctx, eik_den
         ctx.weff, ctx.packed, ctx.variance = weff, packed, variance
-        ctx.NS = (N, S)
-        gradients_o = pctx.view("go").view(N, S, 3)
+        ctx.geom = (rays, z, float(sample_dist), float(cos_anneal))
+        gradients_o = pctx.view("go").view(N, S, 3).clone()       # own storage: the 8 GB workspace must not outlive backward
         ctx.mark_non_differentiable(out["wmax_idx"])
         return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"]
 
@@ -258,19 +263,22 @@ class _RenderFn(torch.autograd.Function):
         eng, pctx = ctx.eng, ctx.pctx
         if not (pctx.flags & _lib.PF_SAVE):
             raise RuntimeError("render was run without saved activations; cannot backpropagate")
-        N, S = ctx.NS
+        rays, zs, sample_dist, cos_anneal = ctx.geom
+        N, S = zs.shape
+        var = ctx.variance.detach()
+        a = eng.composite_args(rays, zs, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var.reshape(1), sample_dist, cos_anneal)
         z = lambda g, *shape: (g.contiguous() if g is not None else eng.zeros(*shape))
-        bw = eng.composite_backward(ctx.a, z(g_color, N, 3), z(g_depth, N, 1).view(-1), z(g_eik, 1).reshape(1), ctx.eik_den,
+        bw = eng.composite_backward(a, z(g_color, N, 3), z(g_depth, N, 1).view(-1), z(g_eik, 1).reshape(1), ctx.eik_den,
                                     g_weights=g_weights.contiguous() if g_weights is not None else None,
                                     g_cdf=g_cdf.contiguous() if g_cdf is not None else None,
                                     g_wmax=g_wmax.contiguous().view(-1) if g_wmax is not None else None,
                                     g_gradients_o=g_go.contiguous() if g_go is not None else None)
         dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, bw["d_sdf"], bw["d_go"], bw["d_rgb"])
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852)
-        var = ctx.variance.detach()
         e = torch.exp(var * 10.0)
         inside = ((e >= 1e-6) & (e <= 1e6)).to(e.dtype)
         dvar = (bw["d_invs_acc"][0] * 10.0 * e * inside).reshape(ctx.variance.shape)
+        ctx.pctx = None                                           # release the workspace as soon as it has been consumed
         return dweff, None, dvar, None, None, None, None, None, None
 
 
@@ -324,7 +332,7 @@ class EndoSurfRenderer(nn.Module):
         if c is not None and c[0] == key:
             return c[1], c[2]
         if want_grad:
-            weff, packed = _PackFn.apply(m, self.engine, *plist)
+            weff, packed = _PackFn.apply(weakref.ref(m), self.engine, *plist)
         else:
             with torch.no_grad():
                 weff, packed = self.engine.weightnorm_pack(m._flat, m.use_deform)
