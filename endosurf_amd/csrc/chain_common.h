@@ -127,6 +127,51 @@ __device__ __forceinline__ void for_quads_noacc(int rt0, int nt0, int lane, F&& 
             for (int q = 0; q < 4; ++q) f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo);
 }
 
+// Same as for_quads, additionally passing the linear quad index qi = (ri*NTC + ni)*4 + q (a compile-time constant after
+// unrolling) so that epilogues can consume operands prefetched into registers BEFORE the GEMM (hides HBM latency).
+template <int RTC, int NTC, class F>
+__device__ __forceinline__ void for_quads_qi(f32x16 (&acc)[RTC][NTC], int rt0, int nt0, int lane, F&& f) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[ri][ni][4 * q + 0], acc[ri][ni][4 * q + 1], acc[ri][ni][4 * q + 2], acc[ri][ni][4 * q + 3]};
+                f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v, (ri * NTC + ni) * 4 + q);
+            }
+}
+// rows row..row+3 of every quad of this wave's tile, from a row-major [rows][ld] HBM buffer, into registers
+template <int RTC, int NTC>
+__device__ __forceinline__ void prefetch_quads(float (&buf)[RTC * NTC * 4][4], const float* __restrict__ base, size_t grow0, int ld,
+                                               int rt0, int nt0, int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* p = base + (grow0 + (rt0 + ri) * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + ni) * 32 + lo;
+                float(&b)[4] = buf[(ri * NTC + ni) * 4 + q];
+                b[0] = p[0]; b[1] = p[ld]; b[2] = p[2 * ld]; b[3] = p[3 * ld];
+            }
+}
+// one value per quad (first row of the quad): ReLU masks of the deformation network's value rows
+template <int RTC, int NTC>
+__device__ __forceinline__ void prefetch_quad_heads(float (&buf)[RTC * NTC * 4], const float* __restrict__ base, size_t grow0, int ld,
+                                                    int rt0, int nt0, int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                buf[(ri * NTC + ni) * 4 + q] = base[(grow0 + (rt0 + ri) * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + ni) * 32 + lo];
+}
+
 __device__ __forceinline__ void lds_store_quad(float* At, int col, int row, const float (&v)[4]) {
     *reinterpret_cast<float4*>(&At[swz(col, row)]) = make_float4(v[0], v[1], v[2], v[3]);
 }

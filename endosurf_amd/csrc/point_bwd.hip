@@ -108,14 +108,11 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
         });
     }
     __syncthreads();
-    auto epi = [&](f32x16(&acc)[2][2], int l) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
-        const float* Hl = CH + (size_t)(l - 1) * Mp * 256;
+    auto epi = [&](f32x16(&acc)[2][2], int l, float(&hpre)[16][4]) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
         float* Yl = CY + (size_t)(l - 1) * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float h[4];
-            g_load_quad(Hl, grow0, 256, row, col, h);
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = h[i] > 0.f ? v[i] : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = hpre[qi][i] > 0.f ? v[i] : 0.f;
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Yl, grow0, 256, row, col, v);
         });
@@ -137,12 +134,14 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
                 for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
             }
         }
+        float hpre[16][4];                                                           // h_l, in flight during the GEMM
+        prefetch_quads<2, 2>(hpre, CH + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l < 4 ? CR1 + (l - 1) : (l == 4 ? (int)CR4H : CR5 + (l - 5));
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l);
+        epi(acc, l, hpre);
         __syncthreads();
     }
     {   // layer 0: adjoint of the network input
@@ -267,16 +266,14 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
     float* TAU = wsb(a, WS_S_TAU);
     float* ZB = wsb(a, WS_S_ZB);
     // ---- (i) forward tangent sweep ----
-    auto epi_t = [&](f32x16(&acc)[2][2], int l) {   // acc = pi_l
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4], r[4], z2[4];
-            g_load_quad(SACT + (size_t)l * Mp * 256, grow0, 256, row, col, s);
-            g_load_quad(RHO + (size_t)l * Mp * 256, grow0, 256, row, col, r);
+    auto epi_t = [&](f32x16(&acc)[2][2], int l, float(&spre)[16][4], float(&rpre)[16][4]) {   // acc = pi_l
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+            float z2[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float dphi = softplus100_grad_from_s(s[i]);
-                z2[i] = 100.f * (1.f - dphi) * r[i] * v[i];      // softplus'' / softplus' = 100 (1 - softplus')
-                v[i] = dphi * v[i];                               // tau_{l+1}
+                const float dphi = softplus100_grad_from_s(spre[qi][i]);
+                z2[i] = 100.f * (1.f - dphi) * rpre[qi][i] * v[i];      // softplus'' / softplus' = 100 (1 - softplus')
+                v[i] = dphi * v[i];                                     // tau_{l+1}
             }
             lds_store_quad(mainT, col, row, v);
             g_store_quad(TAU + (size_t)l * Mp * 256, grow0, 256, row, col, v);
@@ -284,31 +281,34 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
         });
     };
     {
+        float spre[16][4], rpre[16][4];
+        prefetch_quads<2, 2>(spre, SACT, grow0, 256, 0, 2 * wave, lane);
+        prefetch_quads<2, 2>(rpre, RHO, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
-        epi_t(acc, 0);
+        epi_t(acc, 0, spre, rpre);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
+        float spre[16][4], rpre[16][4];
+        prefetch_quads<2, 2>(spre, SACT + (size_t)l * Mp * 256, grow0, 256, 0, 2 * wave, lane);
+        prefetch_quads<2, 2>(rpre, RHO + (size_t)l * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
         __syncthreads();
-        epi_t(acc, l);
+        epi_t(acc, l, spre, rpre);
         __syncthreads();
     }
     // ---- (ii) reverse sweep of the value pass, seeded with zbar_8 = [sdfbar | featbar] ----
-    auto epi_b = [&](f32x16(&acc)[2][2], int l) {   // acc = sbar_l (adjoint of s_l); zbar_{l-1} = phi'(z_{l-1}) sbar_l + second-order
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4], z2[4];
-            g_load_quad(SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, s);
-            g_load_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, z2);
+    auto epi_b = [&](f32x16(&acc)[2][2], int l, float(&spre)[16][4], float(&zpre)[16][4]) {   // acc = sbar_l; zbar_{l-1} = phi'(z_{l-1}) sbar_l + 2nd order
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
+            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(spre[qi][i]) * v[i] + zpre[qi][i];
             lds_store_quad(mainT, col, row, v);
             g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
         });
@@ -341,6 +341,9 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
     for (int l = 7; l >= 1; --l) {
         f32x16 acc[2][2];
         acc_zero(acc);
+        float spre[16][4], zpre[16][4];
+        prefetch_quads<2, 2>(spre, SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
+        prefetch_quads<2, 2>(zpre, ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         f32x16 accA[1][1];
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);
         }
         __syncthreads();
-        epi_b(acc, l);
+        epi_b(acc, l, spre, zpre);
         if (l == 4)
             for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
         __syncthreads();
@@ -428,16 +431,18 @@ __global__ __launch_bounds__(NTHREADS) void k_deform_bwd(BwdArgs a) {
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
+        const float* Ul = U + (size_t)(l - 1) * rows4 * 256;
+        float upre[16];                                                               // value-row activations, in flight during the GEMM
+        prefetch_quad_heads<2, 2>(upre, Ul, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
         else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR1 + (l - 1)], 0, 2 * wave, lane);
         __syncthreads();
-        const float* Ul = U + (size_t)(l - 1) * rows4 * 256;
         float* Al = DA + (size_t)(l - 1) * rows4 * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             // layer 3 has 204 outputs: the skip's encoding part (cols >= 204) carries no parameter gradient
-            const bool m = (l == 4 && col >= 204) ? false : Ul[(grow0 + row) * 256 + col] > 0.f;
+            const bool m = (l == 4 && col >= 204) ? false : upre[qi] > 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = m ? v[i] : 0.f;
             lds_store_quad(mainT, col, row, v);

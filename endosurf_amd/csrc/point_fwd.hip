@@ -229,6 +229,9 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
+        const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
+        float spre[16][4];                                                                         // in flight during the GEMM
+        prefetch_quads<2, 2>(spre, Sl, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
@@ -239,12 +242,9 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
         }
         __syncthreads();
-        const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4];
-            g_load_quad(Sl, grow0, 256, row, col, s);
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(s[i]);
+            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(spre[qi][i]);
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(RHO + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
         });

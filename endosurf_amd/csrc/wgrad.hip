@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X
     const int k = threadIdx.x;
     const int m0 = blockIdx.x * MC, m1 = min(m0 + MC, M);
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int m = m0; m < m1; ++m) {
         const float x = k < K ? X[(size_t)m * ldx + k] : 0.f;
 #pragma unroll
@@ -152,9 +153,9 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
 }
 static void launch_small(const float* X, int ldx, const float* dA, int lda, int M, int K, int N, float* out, int ldo, float* bias_out,
                          int bias_stride, hipStream_t st) {
-    int MC = (M + 255) / 256;
-    MC = (MC + 63) / 64 * 64;
-    if (MC < 64) MC = 64;
+    int MC = (M + 4095) / 4096;        // up to 4096 blocks: the kernel is a pure stream over X
+    MC = (MC + 31) / 32 * 32;
+    if (MC < 32) MC = 32;
     ScopedTimer tm(KID_WGRAD_SMALL, M, st);
     hipLaunchKernelGGL(k_wgrad_small, dim3((M + MC - 1) / MC), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride, MC);
 }
