@@ -27,69 +27,111 @@ struct WgArgs {
     int nprob, total_tasks, MC;
 };
 
-__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (task >= a.total_tasks) return;
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < a.nprob; ++i)
-        if (task >= a.p[i].task_begin) pi = i;
-    const WgProb& P = a.p[pi];
-    const int kblk = (P.K + 63) / 64, nblk = (P.N + 63) / 64;
-    const int local = task - P.task_begin;
-    const int kb = local % kblk, nb = (local / kblk) % nblk, mc = local / (kblk * nblk);
-    const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
-    const int lo = lane & 31, hi = lane >> 5;
-    const float* Ap = P.dA + (size_t)(m0 + hi) * P.lda + nb * 64 + 2 * lo;
-    const float* Bp = P.X + (size_t)(m0 + hi) * P.ldx + kb * 64 + 2 * lo;
-    const bool do_bias = P.bias_out != nullptr && kb == 0;
-    const int bstride = P.bias_stride;
+// One workgroup (8 waves) = one task: a [256 x KW] tile of dW (all 256 output features x KW input features) over a
+// chunk of rows.  Both operand panels are staged through LDS in 16-row stages (double buffered, one barrier per stage), so
+// every dA / X element is read from HBM once per task instead of once per 64x64 wave tile.
+// wave w: n-block nb = w&3 (64 features, 2 MFMA tiles interleaved 2i+t), k-half kh = w>>2 (KTW tiles interleaved 2j+t').
+constexpr int WG_THREADS = 512;
+constexpr int WG_R = 16;                         // rows per stage
+constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + 256);
 
-    f32x16 acc[2][2];
+template <int KTW>
+__device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds) {
+    constexpr int KW = 64 * KTW;                 // input features per task
+    constexpr int BJ = KW / 128;                 // float4 loads of the X panel per thread per stage (KW=128 -> 1, 256 -> 2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = w & 3, kh = w >> 2;
+    const int lo = lane & 31, hi = lane >> 5;
+    auto Apan = [&](int buf) { return lds + buf * (WG_R * 256); };
+    auto Bpan = [&](int buf) { return lds + 2 * WG_R * 256 + buf * (WG_R * KW); };
+    const int kcol0 = kb * KW;
+
+    f32x16 acc[2][KTW];
     acc_zero(acc);
     float bs0 = 0.f, bs1 = 0.f;
-    constexpr int U = 8;   // k-steps (pairs of rows) per register set
-    float2 a0[U], b0[U], a1[U], b1[U];
-    auto load = [&](float2(&av)[U], float2(&bv)[U], int m) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (m + 2 * u < m1) {
-                av[u] = *reinterpret_cast<const float2*>(Ap + (size_t)(m - m0 + 2 * u) * P.lda);
-                bv[u] = *reinterpret_cast<const float2*>(Bp + (size_t)(m - m0 + 2 * u) * P.ldx);
-            } else {
-                av[u] = make_float2(0.f, 0.f); bv[u] = make_float2(0.f, 0.f);
-            }
-        }
-    };
-    auto comp = [&](const float2(&av)[U], const float2(&bv)[U], int m) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc[1][1], 0, 0, 0);
-            if (do_bias && ((m + 2 * u + hi) % bstride) == 0) { bs0 += av[u].x; bs1 += av[u].y; }
-        }
-    };
-    load(a0, b0, m0);
-#pragma unroll 1
-    for (int m = m0; m < m1; m += 4 * U) {
-        load(a1, b1, m + 2 * U);
-        comp(a0, b0, m);
-        load(a0, b0, m + 4 * U);
-        comp(a1, b1, m + 2 * U);
+    const bool do_bias = P.bias_out != nullptr && kb == 0 && kh == 0;
+
+    // global -> register loads of one 16-row stage (two stages are kept in flight: sets 0/1), register -> LDS stores.
+    // Plain ext-vector locals (not HIP float4 structs) so that they stay in VGPRs.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f vzero = {0.f, 0.f, 0.f, 0.f};
+    const int fa0 = tid, fa1 = tid + WG_THREADS;
+    const size_t offA0 = (size_t)(fa0 >> 6) * P.lda + 4 * (fa0 & 63), offA1 = (size_t)(fa1 >> 6) * P.lda + 4 * (fa1 & 63);
+    const int colB0 = kcol0 + 4 * (fa0 % (KW / 4)), colB1 = kcol0 + 4 * (fa1 % (KW / 4));
+    const size_t offB0 = (size_t)(fa0 / (KW / 4)) * P.ldx + colB0, offB1 = (size_t)(fa1 / (KW / 4)) * P.ldx + colB1;
+    const bool okB0 = colB0 < P.ldx, okB1 = colB1 < P.ldx;
+#define WG_GLOAD(A0, A1, B0, B1, m)                                                                   \
+    {                                                                                                 \
+        const float* pa = P.dA + (size_t)(m) * P.lda;                                                 \
+        const float* pb = P.X + (size_t)(m) * P.ldx;                                                  \
+        A0 = *reinterpret_cast<const v4f*>(pa + offA0);                                               \
+        A1 = *reinterpret_cast<const v4f*>(pa + offA1);                                               \
+        B0 = okB0 ? *reinterpret_cast<const v4f*>(pb + offB0) : vzero;                                \
+        if (BJ == 2) B1 = okB1 ? *reinterpret_cast<const v4f*>(pb + offB1) : vzero;                   \
     }
-    // acc[t][t'][r]: n = nb*64 + 2*i + t with i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*64 + 2*lo + t'
+#define WG_SSTORE(A0, A1, B0, B1, buf)                                                                \
+    {                                                                                                 \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa0) = A0;                                            \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = A1;                                            \
+        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * fa0) = B0;                                            \
+        if (BJ == 2) *reinterpret_cast<v4f*>(Bpan(buf) + 4 * fa1) = B1;                               \
+    }
+    auto compute = [&](int buf, int m) {
+        const float* A = Apan(buf) + nb * 64 + 2 * lo;
+        const float* B = Bpan(buf) + kh * (KW / 2) + 2 * lo;
+#pragma unroll
+        for (int s = 0; s < WG_R / 2; ++s) {
+            const float2 av = *reinterpret_cast<const float2*>(A + (2 * s + hi) * 256);
+            float2 bv[KTW / 2];
+#pragma unroll
+            for (int jj = 0; jj < KTW / 2; ++jj) bv[jj] = *reinterpret_cast<const float2*>(B + (2 * s + hi) * KW + jj * 64);
+#pragma unroll
+            for (int jj = 0; jj < KTW / 2; ++jj) {
+                acc[0][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].x, acc[0][2 * jj], 0, 0, 0);
+                acc[0][2 * jj + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].y, acc[0][2 * jj + 1], 0, 0, 0);
+                acc[1][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jj].x, acc[1][2 * jj], 0, 0, 0);
+                acc[1][2 * jj + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jj].y, acc[1][2 * jj + 1], 0, 0, 0);
+            }
+            if (do_bias && ((m + 2 * s + hi) % P.bias_stride) == 0) { bs0 += av.x; bs1 += av.y; }
+        }
+    };
+
+    // software pipeline: stage st computes from LDS[st&1] while the loads of stages st+1 (landing) and st+2 (just issued)
+    // are in flight; one barrier per stage.  nst is even (chunks are multiples of 64 rows).
+    const int nst = (m1 - m0) / WG_R;
+    v4f p0a0, p0a1, p0b0, p0b1 = vzero, p1a0, p1a1, p1b0, p1b1 = vzero;
+    WG_GLOAD(p0a0, p0a1, p0b0, p0b1, m0);
+    WG_GLOAD(p1a0, p1a1, p1b0, p1b1, m0 + WG_R);
+    WG_SSTORE(p0a0, p0a1, p0b0, p0b1, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 2 < nst) WG_GLOAD(p0a0, p0a1, p0b0, p0b1, m0 + WG_R * (st + 2));
+        compute(0, m0 + WG_R * st);
+        WG_SSTORE(p1a0, p1a1, p1b0, p1b1, 1);            // stage st+1 (loaded one iteration ago)
+        __syncthreads();
+        if (st + 3 < nst) WG_GLOAD(p1a0, p1a1, p1b0, p1b1, m0 + WG_R * (st + 3));
+        compute(1, m0 + WG_R * (st + 1));
+        if (st + 2 < nst) WG_SSTORE(p0a0, p0a1, p0b0, p0b1, 0);   // stage st+2
+        __syncthreads();
+    }
+#undef WG_GLOAD
+#undef WG_SSTORE
+    // acc[t][2jj+tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*KW + kh*KW/2 + jj*64 + 2*lo + tp
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-            const int k = kb * 64 + 2 * lo + tp;
+        for (int jt = 0; jt < KTW; ++jt) {
+            const int k = kcol0 + kh * (KW / 2) + (jt >> 1) * 64 + 2 * lo + (jt & 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + t;
-                if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
+#ifdef WG_NO_ATOMIC
+                if (n < P.N && k < P.K) P.out[(size_t)n * P.ldo + k] = acc[t][jt][r];
+#else
+                if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][jt][r]);
+#endif
             }
         }
     if (do_bias) {
@@ -101,6 +143,23 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
             if (n + 1 < P.N) atomicAdd(P.bias_out + n + 1, bs1);
         }
     }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int task = blockIdx.x;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.nprob; ++i)
+        if (task >= a.p[i].task_begin) pi = i;
+    const WgProb& P = a.p[pi];
+    const int local = task - P.task_begin;
+    const bool narrow = P.K <= 128;
+    const int kblk = narrow ? 1 : (P.K + 255) / 256;
+    const int kb = local % kblk, mc = local / kblk;
+    const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
+    if (narrow) wgrad_task<2>(P, kb, m0, m1, wlds);
+    else wgrad_task<4>(P, kb, m0, m1, wlds);
 }
 
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256).
@@ -129,26 +188,34 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X
         for (int n = 0; n < N; ++n) atomicAdd(bias_out + n, bs[n]);
 }
 
+static int wg_kblk(const WgProb& p) { return p.K <= 128 ? 1 : (p.K + 255) / 256; }
+
 static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (int e = allow_big_lds(k_wgrad, WG_LDS_FLOATS * 4)) return e;
+        attr_done = true;
+    }
     if (nprob == 0) return ST_OK;
     ES_REQUIRE(nprob <= WG_MAX_PROBS, "too many weight-gradient problems in one group");
-    // rows per task: aim at a few thousand wavefront tasks per launch
+    // rows per task: aim at ~2 tasks per CU per launch (each task owns a CU: 8 waves, 64 KB LDS)
     double work = 0;
-    for (int i = 0; i < nprob; ++i) work += (double)probs[i].M * ((probs[i].K + 63) / 64) * ((probs[i].N + 63) / 64);
-    int MC = (int)(work / 3072.0);
+    for (int i = 0; i < nprob; ++i) work += (double)probs[i].M * wg_kblk(probs[i]);
+    int MC = (int)(work / 640.0);
     MC = (MC + 63) / 64 * 64;
-    if (MC < 256) MC = 256;
+    if (MC < 128) MC = 128;
     if (MC > 8192) MC = 8192;
     WgArgs a;
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
+        ES_REQUIRE(probs[i].lda == 256 && probs[i].M % 64 == 0, "weight-gradient operands must be [64k][256] adjoints");
         probs[i].task_begin = total;
-        total += ((probs[i].K + 63) / 64) * ((probs[i].N + 63) / 64) * ((probs[i].M + MC - 1) / MC);
+        total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
         a.p[i] = probs[i];
     }
     a.nprob = nprob; a.total_tasks = total; a.MC = MC;
     ScopedTimer tm(kid, rows, st);
-    hipLaunchKernelGGL(k_wgrad, dim3((total + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(total), dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
     return ST_OK;
 }
 static void launch_small(const float* X, int ldx, const float* dA, int lda, int M, int K, int N, float* out, int ldo, float* bias_out,
