@@ -16,7 +16,7 @@ _c_float_p = C.c_void_p   # device pointers travel as integers (torch .data_ptr(
 
 class es_points(C.Structure):
     _fields_ = [("x", C.c_void_p), ("t", C.c_void_p), ("dirs", C.c_void_p), ("rays", C.c_void_p), ("z", C.c_void_p),
-                ("mode", C.c_int), ("t_scalar", C.c_int), ("n_per_ray", C.c_int), ("ldz", C.c_int), ("M", C.c_int)]
+                ("mode", C.c_int), ("t_scalar", C.c_int), ("n_per_ray", C.c_int), ("ldz", C.c_int), ("M", C.c_int), ("M_split", C.c_int)]
 
 
 class es_composite_args(C.Structure):
@@ -60,8 +60,8 @@ PROTOTYPES = {
     "es_march_finish": (_I, [_P, _P, _I, _P, _P]),
     "es_point_workspace_floats": (C.c_int64, [_I, _I]),
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
-    "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
-    "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
+    "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "es_timing_enable": (_I, [_I]),
     "es_timing_drain": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "es_kernel_name": (C.c_char_p, [_I]),

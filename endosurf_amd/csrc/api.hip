@@ -12,10 +12,10 @@ int weightnorm_pack(const float* params, float* weff, float* packed, int use_def
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
-int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
-int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
-                          const float* d_go, const float* d_rgb, hipStream_t st);
-int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, hipStream_t st);
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
+int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st);
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
 int upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
@@ -34,7 +34,7 @@ static_assert(sizeof(es_points) == sizeof(PointSrc), "es_points must mirror es::
 static inline PointSrc to_src(const es_points* p) {
     PointSrc s;
     s.x = p->x; s.t = p->t; s.dirs = p->dirs; s.rays = p->rays; s.z = p->z;
-    s.mode = p->mode; s.t_scalar = p->t_scalar; s.n_per_ray = p->n_per_ray; s.ldz = p->ldz; s.M = p->M;
+    s.mode = p->mode; s.t_scalar = p->t_scalar; s.n_per_ray = p->n_per_ray; s.ldz = p->ldz; s.M = p->M; s.M_split = p->M_split;
     return s;
 }
 static inline int check_src(const es_points* p) {
@@ -44,8 +44,9 @@ static inline int check_src(const es_points* p) {
     if (p->mode == 0) {
         ES_REQUIRE(p->x && p->t, "mode 0 needs x and t");
     } else {
-        ES_REQUIRE(p->mode == 1, "unknown point-source mode");
-        ES_REQUIRE(p->rays && p->z && p->n_per_ray > 0 && p->ldz >= p->n_per_ray, "mode 1 needs rays, z, n_per_ray <= ldz");
+        ES_REQUIRE(p->mode == 1 || p->mode == 2, "unknown point-source mode");
+        ES_REQUIRE(p->rays && p->z && p->n_per_ray > 0 && p->ldz >= p->n_per_ray, "modes 1/2 need rays, z, n_per_ray <= ldz");
+        if (p->mode == 2) ES_REQUIRE(p->M_split >= 0 && p->M_split <= p->M && (p->M_split == p->M || (p->x && p->t)), "mode 2 needs M_split <= M and x, t");
     }
     return ST_OK;
 }
@@ -165,21 +166,29 @@ int64_t es_point_workspace_offset(int M, int flags, int buffer_id) {
     if (M <= 0 || buffer_id < 0 || buffer_id >= WS_COUNT) return -1;
     return (int64_t)ws_layout(M, flags).off[buffer_id];
 }
-int es_point_forward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, void* stream) {
+static inline int check_mcolor(const es_points* pts, int flags, int m_color) {
+    if (!(flags & ES_PF_COLOR) || m_color <= 0 || m_color == pts->M) return ST_OK;
+    ES_REQUIRE(m_color < pts->M && m_color % 64 == 0, "m_color must be a multiple of 64 (tile aligned) or cover all points");
+    ES_REQUIRE(pts->mode != 2 || m_color <= pts->M_split, "colour points must be ray samples");
+    return ST_OK;
+}
+int es_point_forward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color, void* stream) {
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
-    ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode == 1 || pts->dirs, "colour evaluation needs view directions");
-    return point_forward(to_src(pts), packed, weff, ws, flags, (hipStream_t)stream);
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    return point_forward(to_src(pts), packed, weff, ws, flags, m_color, (hipStream_t)stream);
 }
 
-int es_point_backward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
-                      const float* d_go, const float* d_rgb, float* dweff, void* stream) {
+int es_point_backward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                      const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, void* stream) {
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(flags & ES_PF_SAVE, "es_point_backward needs a workspace produced with ES_PF_SAVE");
     ES_REQUIRE(packed && weff && dweff && (pts->M == 0 || (ws && d_sdf && d_go)), "null buffer");
     ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
-    if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
-    return point_wgrad(pts->M, ws, flags, d_sdf, dweff, (hipStream_t)stream);
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
+    return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -254,6 +254,8 @@ __device__ __forceinline__ float smalln_reduce(const float* scr, int i, int row)
 // mode 0: explicit x[M][3], t[M] (or t[0] if t_scalar);  optional dirs[M][3]
 // mode 1: ray samples: point i -> ray i / n, sample i % n:  x = o + d/(d.z+1e-6) * z[ray*ldz + s], t = rays[ray][8],
 //         dir = rays[ray][3:6]   (reference endosurf.py:66, 87, 153)
+// mode 2: the first M_split points are ray samples (as mode 1), the remaining M - M_split are explicit (x, t) without dirs:
+//         lets the training step evaluate its auxiliary points (errorondepth / surface neighbours) in the render launch
 struct PointSrc {
     const float* x;
     const float* t;
@@ -261,11 +263,13 @@ struct PointSrc {
     const float* rays;
     const float* z;
     int mode, t_scalar, n_per_ray, ldz;
-    int M;
+    int M, M_split;
 };
-__device__ __forceinline__ void load_point(const PointSrc& s, int i, float (&x)[3], float& t, float (&d)[3]) {
+__device__ __forceinline__ void load_point(const PointSrc& s, int i_in, float (&x)[3], float& t, float (&d)[3]) {
+    int i = i_in;
     if (i >= s.M) { x[0] = x[1] = x[2] = 0.f; t = 0.f; d[0] = d[1] = 0.f; d[2] = 1.f; return; }
-    if (s.mode == 0) {
+    if (s.mode == 0 || (s.mode == 2 && i >= s.M_split)) {
+        if (s.mode == 2) i -= s.M_split;
         x[0] = s.x[3 * (size_t)i]; x[1] = s.x[3 * (size_t)i + 1]; x[2] = s.x[3 * (size_t)i + 2];
         t = s.t[s.t_scalar ? 0 : i];
         if (s.dirs) { d[0] = s.dirs[3 * (size_t)i]; d[1] = s.dirs[3 * (size_t)i + 1]; d[2] = s.dirs[3 * (size_t)i + 2]; }

@@ -24,6 +24,7 @@ struct BwdArgs {
     float* ws;
     WsLayout L;
     int flags;
+    int M_color;       // points [0, M_color) go through the colour network (multiple of 64 unless == M)
     const float* d_sdf;   // [M]
     const float* d_go;    // [M][3]
     const float* d_rgb;   // [M][3] (colour only)
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
 
     if (tid < 64) {
         const size_t gp = grow0 + tid;
-        const bool valid = row0 + tid < a.src.M;
+        const bool valid = row0 + tid < a.M_color;
         float x[3], t;
         load_point(a.src, row0 + tid, x, t, dray);
         const float* rgb = wsb(a, WS_RGB) + gp * 3;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * TM;
     const size_t grow0 = (size_t)row0;
-    const bool deform = a.flags & PF_DEFORM, color = a.flags & PF_COLOR;
+    const bool deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
     const size_t Mp = (size_t)a.L.Mp;
 
     if (tid < 64) {
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(NTHREADS) void k_deform_bwd(BwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, const float* d_sdf,
-                          const float* d_go, const float* d_rgb, hipStream_t st) {
+int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_color_bwd, LDS_BYTES)) return e;
@@ -466,8 +467,9 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     BwdArgs a;
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags; a.d_sdf = d_sdf; a.d_go = d_go; a.d_rgb = d_rgb;
-    const int Mp = a.L.Mp;
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, src.M, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
+    const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_backward_chains");

@@ -23,6 +23,7 @@ struct FwdArgs {
     float* ws;
     WsLayout L;
     int flags;
+    int M_color;       // points [0, M_color) go through the colour network (multiple of 64 unless == M)
 };
 
 __device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws + a.L.off[buf]; }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * TM;
     const size_t grow0 = (size_t)row0;
-    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM, color = a.flags & PF_COLOR;
+    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
     const size_t Mp = (size_t)a.L.Mp;
 
     if (tid < 64) {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st) {
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_deform_fwd, LDS_BYTES)) return e;
@@ -406,10 +407,11 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     FwdArgs a;
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags;
-    const int Mp = a.L.Mp;
+    a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
+    const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, src.M, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_forward");
 }
 

@@ -11,7 +11,10 @@
 
 namespace es {
 
-template <bool DEFORM>
+// HALF: latency-bound small batches (secant iterations, 8-sample up-sampling queries) use 32-point tiles: the LDS tile keeps
+// its 64-row layout but only row-tile 0 carries points, so every layer issues half the MFMAs and twice as many workgroups
+// share the batch.
+template <bool DEFORM, bool HALF>
 __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, const float4* __restrict__ packed,
                                                         const float* __restrict__ weff, float* __restrict__ sdf_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -23,11 +26,13 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
     float* red = scr + 256;   // [4][<=3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * TM;
+    constexpr int RTC = HALF ? 1 : 2;
+    constexpr int PTS = HALF ? 32 : 64;
+    const int row0 = blockIdx.x * PTS;
 
     if (tid < 64) {
         float x[3], t, d[3];
-        load_point(src, row0 + tid, x, t, d);
+        load_point(src, tid < PTS ? row0 + tid : src.M, x, t, d);
         px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2]; pt[tid] = t;
     }
     __syncthreads();
@@ -39,9 +44,9 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
         zero_rows(aux, 52, 56, tid);
         __syncthreads();
         {
-            f32x16 acc[2][2];
+            f32x16 acc[RTC][2];
             acc_zero(acc);
-            gemm_seg<7, 2, 2>(acc, aux, packed + tb.segoff[DF0], 0, 2 * wave, lane);
+            gemm_seg<7, RTC, 2>(acc, aux, packed + tb.segoff[DF0], 0, 2 * wave, lane);
             const float* bias = weff + tb.boff[NET_D * LAYERS + 0];
             for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
                 const float b = bias[col];
@@ -53,9 +58,9 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
-            f32x16 acc[2][2];
+            f32x16 acc[RTC][2];
             acc_zero(acc);
-            gemm_seg<32, 2, 2>(acc, mainT, packed + tb.segoff[DF0 + l], 0, 2 * wave, lane);
+            gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[DF0 + l], 0, 2 * wave, lane);
             __syncthreads();
             const float* bias = weff + tb.boff[NET_D * LAYERS + l];
             for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
     zero_rows(aux, 39, 40, tid);
     __syncthreads();
     {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
-        gemm_seg<5, 2, 2>(acc, aux, packed + tb.segoff[SF0], 0, 2 * wave, lane);
+        gemm_seg<5, RTC, 2>(acc, aux, packed + tb.segoff[SF0], 0, 2 * wave, lane);
         const float* bias = weff + tb.boff[NET_S * LAYERS + 0];
         for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
             const float b = bias[col];
@@ -98,11 +103,11 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
-        gemm_seg<32, 2, 2>(acc, mainT, packed + tb.segoff[seg], 0, 2 * wave, lane);
-        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, packed + tb.segoff[SF4A], 0, 2 * wave, lane);   // NeRF skip: + enc part
+        gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[seg], 0, 2 * wave, lane);
+        if (l == 4) gemm_seg<5, RTC, 2>(acc, aux, packed + tb.segoff[SF4A], 0, 2 * wave, lane);   // NeRF skip: + enc part
         __syncthreads();
         const float* bias = weff + tb.boff[NET_S * LAYERS + l];
         for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
@@ -115,24 +120,32 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
     }
     smalln_partial<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
     __syncthreads();
-    if (tid < 64 && row0 + tid < src.M) sdf_out[row0 + tid] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+    if (tid < PTS && row0 + tid < src.M) sdf_out[row0 + tid] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
 }
 
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_query_sdf<true>, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf<false>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<true, false>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<false, false>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<true, true>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<false, true>, LDS_BYTES)) return e;
         attr_done = true;
     }
     if (src.M <= 0) return ST_OK;
     const Tabs tb = make_tabs();
-    const dim3 grid((src.M + TM - 1) / TM), block(NTHREADS);
+    const bool half = src.M <= 16384;      // fewer than one 64-point tile per CU: halve the tile instead of idling CUs
+    const int pts = half ? 32 : 64;
+    const dim3 grid((src.M + pts - 1) / pts), block(NTHREADS);
+    const float4* pk = reinterpret_cast<const float4*>(packed);
     ScopedTimer tm(KID_QUERY, src.M, st);
-    if (use_deform)
-        hipLaunchKernelGGL(k_query_sdf<true>, grid, block, LDS_BYTES, st, src, tb, reinterpret_cast<const float4*>(packed), weff, sdf_out);
-    else
-        hipLaunchKernelGGL(k_query_sdf<false>, grid, block, LDS_BYTES, st, src, tb, reinterpret_cast<const float4*>(packed), weff, sdf_out);
+    if (use_deform) {
+        if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+    } else {
+        if (half) hipLaunchKernelGGL((k_query_sdf<false, true>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        else hipLaunchKernelGGL((k_query_sdf<false, false>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+    }
     return hip_last("query_sdf");
 }
 

@@ -228,11 +228,12 @@ static void launch_small(const float* X, int ldx, const float* dA, int lda, int 
 }
 
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
-int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, hipStream_t st) {
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st) {
     if (M <= 0) return ST_OK;
     const WsLayout L = ws_layout(M, flags);
     const Tabs tb = make_tabs();
     const int Mp = L.Mp;
+    const int Mc = (flags & PF_COLOR) ? round_up64(m_color > 0 ? m_color : M) : 0;   // rows that went through the colour network
     const size_t t256 = (size_t)Mp * 256;
     auto B = [&](int buf) { return ws + L.off[buf]; };
     auto dW = [&](int net, int l) { return dweff + tb.woff[net * LAYERS + l]; };
@@ -267,7 +268,7 @@ int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, h
             }
         }
         if (flags & PF_COLOR)   // feature rows 1..256 of the last layer
-            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mp, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
+            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
         if (int e = launch_group(g, n, KID_WGRAD_S, M, st)) return e;
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
         launch_small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, st);   // real rows only: d_sdf is [M]
@@ -275,18 +276,18 @@ int point_wgrad(int M, float* ws, int flags, const float* d_sdf, float* dweff, h
     }
     if (flags & PF_COLOR) {
         n = 0;
-        add(B(WS_C_IN), 128, B(WS_C_Y), 256, Mp, 93, 256, dW(NET_C, 0), 349, dB(NET_C, 0), 1);
-        add(B(WS_FEAT), 256, B(WS_C_Y), 256, Mp, 256, 256, dW(NET_C, 0) + 93, 349, nullptr, 1);
+        add(B(WS_C_IN), 128, B(WS_C_Y), 256, Mc, 93, 256, dW(NET_C, 0), 349, dB(NET_C, 0), 1);
+        add(B(WS_FEAT), 256, B(WS_C_Y), 256, Mc, 256, 256, dW(NET_C, 0) + 93, 349, nullptr, 1);
         for (int l = 1; l <= 7; ++l) {
             const int K = LAYER_K[NET_C][l];
-            add(B(WS_C_H) + (size_t)(l - 1) * t256, 256, B(WS_C_Y) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_C, l), K, dB(NET_C, l), 1);
+            add(B(WS_C_H) + (size_t)(l - 1) * t256, 256, B(WS_C_Y) + (size_t)l * t256, 256, Mc, 256, 256, dW(NET_C, l), K, dB(NET_C, l), 1);
             if (l == 4) {
-                add(B(WS_C_IN), 128, B(WS_C_Y) + (size_t)4 * t256, 256, Mp, 93, 256, dW(NET_C, 4) + 256, K, nullptr, 1);
-                add(B(WS_FEAT), 256, B(WS_C_Y) + (size_t)4 * t256, 256, Mp, 256, 256, dW(NET_C, 4) + 349, K, nullptr, 1);
+                add(B(WS_C_IN), 128, B(WS_C_Y) + (size_t)4 * t256, 256, Mc, 93, 256, dW(NET_C, 4) + 256, K, nullptr, 1);
+                add(B(WS_FEAT), 256, B(WS_C_Y) + (size_t)4 * t256, 256, Mc, 256, 256, dW(NET_C, 4) + 349, K, nullptr, 1);
             }
         }
-        if (int e = launch_group(g, n, KID_WGRAD_C, M, st)) return e;
-        launch_small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mp, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1, st);
+        if (int e = launch_group(g, n, KID_WGRAD_C, Mc, st)) return e;
+        launch_small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1, st);
     }
     return hip_last("point_wgrad");
 }

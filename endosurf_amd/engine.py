@@ -57,14 +57,22 @@ class Engine:
     # ---- point sources ----------------------------------------------------------------------------
     @staticmethod
     def points(x=None, t=None, dirs=None, rays=None, z=None, n_per_ray=1, ldz=None, M=None) -> es_points:
+        """mode 0: explicit (x, t[, dirs]); mode 1: ray samples (rays, z); mode 2: ray samples followed by explicit (x, t)."""
         p = es_points()
         if rays is not None:
-            p.mode = 1
             p.rays, p.z = ptr(rays), ptr(z)
             p.n_per_ray = int(n_per_ray)
             p.ldz = int(ldz if ldz is not None else z.shape[-1])
-            p.M = int(M if M is not None else rays.shape[0] * n_per_ray)
-            p._keep = (rays, z)
+            n_ray_pts = rays.shape[0] * n_per_ray
+            if x is not None:
+                p.mode, p.M_split = 2, n_ray_pts
+                p.x, p.t = ptr(x), ptr(t)
+                p.t_scalar = 0
+                p.M = n_ray_pts + x.shape[0]
+            else:
+                p.mode = 1
+                p.M = int(M if M is not None else n_ray_pts)
+            p._keep = (rays, z, x, t)
         else:
             p.mode = 0
             p.x, p.t = ptr(x), ptr(t)
@@ -194,8 +202,8 @@ class PointCtx:
     _OUT = {"xc": (_lib.WS_XC, 3), "J": (_lib.WS_J, 9), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
             "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3)}
 
-    def __init__(self, eng: "Engine", pts, flags: int):
-        self.eng, self.pts, self.flags, self.M = eng, pts, flags, pts.M
+    def __init__(self, eng: "Engine", pts, flags: int, m_color: int = 0):
+        self.eng, self.pts, self.flags, self.M, self.m_color = eng, pts, flags, pts.M, int(m_color)
         self.Mp = (self.M + 63) // 64 * 64
         n = int(eng.lib.es_point_workspace_floats(self.M, flags))
         self.ws = eng.empty(max(n, 1))
@@ -207,9 +215,9 @@ class PointCtx:
         return v
 
 
-def _point_forward(self, pts, weff, packed, flags: int) -> PointCtx:
-    ctx = PointCtx(self, pts, flags)
-    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, stream_ptr()), "es_point_forward")
+def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
+    ctx = PointCtx(self, pts, flags, m_color)
+    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), stream_ptr()), "es_point_forward")
     return ctx
 
 
@@ -222,9 +230,12 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None):
     z = lambda g, w: (g.detach().to(torch.float32).contiguous() if g is not None else self.zeros(M, w))
     d_sdf, d_go = z(d_sdf, 1), z(d_go, 3)
     color = bool(ctx.flags & _lib.PF_COLOR)
-    d_rgb = z(d_rgb, 3) if color else None
+    if color:
+        mc = ctx.m_color if ctx.m_color > 0 else M
+        d_rgb = d_rgb.detach().to(torch.float32).contiguous() if d_rgb is not None else self.zeros(mc, 3)
+        assert d_rgb.shape[0] == mc
     dweff = self.zeros(self.n_weff)
-    check(self.lib.es_point_backward(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ptr(d_sdf), ptr(d_go),
+    check(self.lib.es_point_backward(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
                                      ptr(d_rgb) if color else None, ptr(dweff), stream_ptr()), "es_point_backward")
     return dweff
 

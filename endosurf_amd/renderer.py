@@ -238,33 +238,41 @@ class _PointEvalFn(torch.autograd.Function):
 
 class _RenderFn(torch.autograd.Function):
     """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing.
-    (ctx keeps inputs and the workspace only, never the outputs: see _PackFn.)"""
+    Optionally evaluates ``aux_x/aux_t`` (colour-less points: errorondepth / surface-neighbour points of a training step)
+    in the SAME kernel launches and returns their (sdf, g_o).  ctx keeps inputs and the workspace only, never outputs."""
 
     @staticmethod
-    def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int):
+    def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int, aux_x, aux_t):
         N, S = z.shape
+        P_ = N * S
         mid = eng.mid_z(z, sample_dist)
-        pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S)
-        pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR)
+        fused = aux_x is not None and aux_x.shape[0] > 0 and P_ % 64 == 0
+        pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=aux_x if fused else None, t=aux_t if fused else None)
+        pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR, m_color=P_ if fused else 0)
         var1 = variance.detach().reshape(1)
-        a = eng.composite_args(rays, z, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
+        sdf_all, go_all = pctx.view("sdf"), pctx.view("go")
+        a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
         out = eng.composite_forward(a)
         eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
         eik = out["eik_acc"][0] / eik_den[0]
         ctx.eng, ctx.pctx, ctx.eik_den = eng, pctx, eik_den
         ctx.weff, ctx.packed, ctx.variance = weff, packed, variance
         ctx.geom = (rays, z, float(sample_dist), float(cos_anneal))
-        gradients_o = pctx.view("go").view(N, S, 3).clone()       # own storage: the 8 GB workspace must not outlive backward
+        ctx.n_aux = aux_x.shape[0] if fused else 0
+        gradients_o = go_all[:P_].view(N, S, 3).clone()           # own storage: the 8 GB workspace must not outlive backward
+        aux_sdf = sdf_all[P_:].clone() if fused else eng.zeros(0, 1)
+        aux_go = go_all[P_:].clone() if fused else eng.zeros(0, 3)
         ctx.mark_non_differentiable(out["wmax_idx"])
-        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"]
+        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf, aux_go
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _):
+    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go):
         eng, pctx = ctx.eng, ctx.pctx
         if not (pctx.flags & _lib.PF_SAVE):
             raise RuntimeError("render was run without saved activations; cannot backpropagate")
         rays, zs, sample_dist, cos_anneal = ctx.geom
         N, S = zs.shape
+        P_ = N * S
         var = ctx.variance.detach()
         a = eng.composite_args(rays, zs, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var.reshape(1), sample_dist, cos_anneal)
         z = lambda g, *shape: (g.contiguous() if g is not None else eng.zeros(*shape))
@@ -273,13 +281,17 @@ class _RenderFn(torch.autograd.Function):
                                     g_cdf=g_cdf.contiguous() if g_cdf is not None else None,
                                     g_wmax=g_wmax.contiguous().view(-1) if g_wmax is not None else None,
                                     g_gradients_o=g_go.contiguous() if g_go is not None else None)
-        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, bw["d_sdf"], bw["d_go"], bw["d_rgb"])
+        d_sdf, d_go = bw["d_sdf"].view(-1, 1), bw["d_go"]
+        if ctx.n_aux:
+            d_sdf = torch.cat([d_sdf, z(g_aux_sdf, ctx.n_aux, 1)], 0)
+            d_go = torch.cat([d_go, z(g_aux_go, ctx.n_aux, 3)], 0)
+        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"])
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852)
         e = torch.exp(var * 10.0)
         inside = ((e >= 1e-6) & (e <= 1e6)).to(e.dtype)
         dvar = (bw["d_invs_acc"][0] * 10.0 * e * inside).reshape(ctx.variance.shape)
         ctx.pctx = None                                           # release the workspace as soon as it has been consumed
-        return dweff, None, dvar, None, None, None, None, None, None
+        return dweff, None, dvar, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -353,9 +365,11 @@ class EndoSurfRenderer(nn.Module):
     def forward(self, rays, **kwargs):
         return self.render_rays(rays, **kwargs)
 
-    def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, **kwargs):
+    def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, aux_points=None, **kwargs):
         """reference render_rays (endosurf.py:60-132).  ``u_perturb`` ([N] or [N,1] uniform draws) may be supplied to
-        make the stratified jitter reproducible; otherwise it is drawn with torch.rand on the device like the reference."""
+        make the stratified jitter reproducible; otherwise it is drawn with torch.rand on the device like the reference.
+        ``aux_points=(x [Ma,3], t [Ma])``: extra colour-less points evaluated in the same launches; their network outputs
+        come back as ``aux_sdf`` [Ma,1] / ``aux_gradients_o`` [Ma,3] (used by the fused training step)."""
         rays = self._rays32(rays)
         n_rays = rays.shape[0]
         weff, packed = self._weights()
@@ -370,9 +384,11 @@ class EndoSurfRenderer(nn.Module):
                                      self.up_sample_steps, upsample)
         sample_dist = 2.0 / self.n_samples
         ret = self.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist,
-                               cos_anneal_ratio=self.get_cos_anneal_ratio(iter_step), eval=eval, _rays=rays)
+                               cos_anneal_ratio=self.get_cos_anneal_ratio(iter_step), eval=eval, _rays=rays, _aux=aux_points)
         n_samples = z.shape[1]
+        extra = {"aux_sdf": ret["aux_sdf"], "aux_gradients_o": ret["aux_gradients_o"]} if aux_points is not None else {}
         return {
+            **extra,
             "color_map": ret["color_map"],
             "depth_map": ret["depth_map"],
             "gradients_o": ret["gradients_o"],
@@ -383,7 +399,7 @@ class EndoSurfRenderer(nn.Module):
             "s_val": ret["s_val"].reshape(1, 1).expand(n_rays, n_samples).mean(dim=-1, keepdim=True),
         }
 
-    def render_core(self, rays_o, rays_d, time, z_vals, sample_dist, cos_anneal_ratio=0.0, eval=False, _rays=None):
+    def render_core(self, rays_o, rays_d, time, z_vals, sample_dist, cos_anneal_ratio=0.0, eval=False, _rays=None, _aux=None):
         """reference render_core (endosurf.py:134-213)."""
         if _rays is None:
             n = rays_o.shape[0]
@@ -391,11 +407,17 @@ class EndoSurfRenderer(nn.Module):
         weff, packed = self._weights()
         var = self.model.deviation_network.variance
         z = z_vals.detach().to(torch.float32).contiguous()
-        color, depth, g_o, eik, weights, wmax, cdf, _ = _RenderFn.apply(weff, packed, var, self.engine, _rays, z, float(sample_dist),
-                                                                     float(cos_anneal_ratio), self._flags(weff))
+        aux_x = aux_t = None
+        if _aux is not None:
+            aux_x = _aux[0].detach().to(torch.float32).contiguous()
+            aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
+        color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go = _RenderFn.apply(
+            weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), self._flags(weff), aux_x, aux_t)
+        if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
+            aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
         return {"color_map": color, "depth_map": depth, "gradients_o": g_o, "gradient_o_error": eik, "cdf": cdf,
-                "weights": weights, "weight_max": wmax, "s_val": 1.0 / inv_s}
+                "weights": weights, "weight_max": wmax, "s_val": 1.0 / inv_s, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
 
     # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
     def _point_eval(self, x, t, dirs=None):
@@ -407,10 +429,18 @@ class EndoSurfRenderer(nn.Module):
 
     def errorondepth(self, rays, d_gt, mask, iter_step=0):
         rays = self._rays32(rays)
+        pts, time = self._eod_points(rays, d_gt)
+        sdf, gradient_o = self._point_eval(pts, time)
+        return self._eod_loss(rays, pts, mask, sdf, gradient_o)
+
+    @staticmethod
+    def _eod_points(rays, d_gt):
         rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
         rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
-        pts = (rays_o + rays_d_z * d_gt).reshape(-1, 3)
-        sdf, gradient_o = self._point_eval(pts, time)
+        return (rays_o + rays_d_z * d_gt).reshape(-1, 3), time
+
+    def _eod_loss(self, rays, pts, mask, sdf, gradient_o):
+        rays_d = rays[:, 3:6]
         true_cos = (rays_d * gradient_o).sum(-1, keepdim=True)
         relu_cos = torch.relu(true_cos)
         pts_norm = torch.linalg.norm(pts.detach(), ord=2, dim=-1, keepdim=True)
@@ -432,6 +462,11 @@ class EndoSurfRenderer(nn.Module):
         """reference surface_neighbour_error (endosurf.py:319-342), evaluated at fixed shape (all rays, masked mean)
         so that no host synchronisation is needed; returns a 0-d tensor (0 when no ray is valid)."""
         rays = self._rays32(rays)
+        pp, tt, valid = self._sn_points(rays, mask, neighbour_rad, u_neigh)
+        _, g = self._point_eval(pp, tt)
+        return self._sn_loss(g, valid)
+
+    def _sn_points(self, rays, mask, neighbour_rad, u_neigh=None):
         N = rays.shape[0]
         rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
         rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
@@ -442,13 +477,13 @@ class EndoSurfRenderer(nn.Module):
             p_surf = rays_o + d_safe * rays_d_z
             u = u_neigh if u_neigh is not None else torch.rand(N, 3, device=self.device)
             p_neig = p_surf + (u.to(torch.float32) - 0.5) * neighbour_rad
-            pp = torch.cat([p_surf, p_neig], 0).contiguous()
-            tt = torch.cat([time, time], 0).contiguous()
-        _, g = self._point_eval(pp, tt)
+            return torch.cat([p_surf, p_neig], 0).contiguous(), torch.cat([time, time], 0).contiguous(), valid
+
+    def _sn_loss(self, g, valid):
+        N = valid.shape[0]
         normal = g / (torch.linalg.norm(g, ord=2, dim=-1, keepdim=True) + 1e-10)
         diff = (normal[:N] - normal[N:]).abs() * valid[:, None].to(self.dtype)
-        n_valid = valid.sum()
-        return diff.sum() / torch.clamp(n_valid * 3, min=1).to(self.dtype)
+        return diff.sum() / torch.clamp(valid.sum() * 3, min=1).to(self.dtype)
 
     # ---- offline helpers (reference endosurf.py:490-521) -----------------------------------------------------------------
     def sdf_observed(self, pts, t):

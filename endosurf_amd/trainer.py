@@ -31,6 +31,30 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
     return total, terms, ret
 
 
+def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
+                       u_perturb=None, u_neigh=None):
+    """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
+    inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
+    rays = renderer._rays32(batch["rays"])
+    color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
+    N = rays.shape[0]
+    eod_pts, time = renderer._eod_points(rays, depth_gt)
+    sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh)
+    aux_x = torch.cat([eod_pts, sn_pts], 0)
+    aux_t = torch.cat([time, sn_t], 0)
+    ret = renderer(rays, iter_step=iter_step, u_perturb=u_perturb, aux_points=(aux_x, aux_t))
+    a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
+    color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
+    sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
+    depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
+    eik = ret["gradient_o_error"]
+    sn = renderer._sn_loss(a_go[N:], valid_sn)
+    total = (color_loss * weights["color"] + depth_loss * weights["depth"] + sdf_loss * weights["sdf"]
+             + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
+    terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
+    return total, terms, ret
+
+
 def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
     """update_learning_rate (trainer_endosurf.py:183-203)."""
     if it < warm_up_end:
@@ -76,7 +100,7 @@ class Trainer:
     """zero_grad -> compute_loss -> backward -> (data-parallel gradient all-reduce) -> Adam  (train_step, trainer_endosurf.py:94-104)."""
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
-                 loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False):
+                 loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True):
         self.renderer = renderer
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
@@ -84,6 +108,7 @@ class Trainer:
         self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
         self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
         self.data_parallel = data_parallel
+        self.loss_fn = compute_loss_fused if fused else compute_loss
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)
@@ -93,7 +118,7 @@ class Trainer:
 
     def train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
         self.optimizer.zero_grad(set_to_none=True)
-        loss, terms, ret = compute_loss(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
+        loss, terms, ret = self.loss_fn(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
         loss.backward()
         if self.data_parallel:
             from .parallel import allreduce_gradients

@@ -63,7 +63,7 @@ def test_layout_queries_match_reference_shapes(lib):
 
 def test_struct_sizes_match_header(lib):
     from endosurf_amd import _lib
-    assert C.sizeof(_lib.es_points) == 5 * 8 + 5 * 4 + 4      # 5 pointers, 5 ints, tail padding to 8
+    assert C.sizeof(_lib.es_points) == 5 * 8 + 6 * 4          # 5 pointers, 6 ints
     assert C.sizeof(_lib.es_composite_args) % 8 == 0
     assert lib.es_point_workspace_floats(0, 7) == 0
     n = lib.es_point_workspace_floats(100, 7)
