@@ -391,12 +391,13 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void k_deform_bwd(BwdArgs a) {
+// LDS: activation tile + 768 B only => two workgroups per CU (2 waves per SIMD): one workgroup's epilogue / barrier
+// phases overlap the other's MFMA stream.
+constexpr int DBWD_LDS_BYTES = (MAIN_FLOATS + 192) * 4;
+__global__ __launch_bounds__(NTHREADS, 2) void k_deform_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
-    float* a8 = scr;   // [3][64]
+    float* a8 = lds + MAIN_FLOATS;   // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt0 = blockIdx.x * 16;
@@ -460,7 +461,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     if (!attr_done) {
         if (int e = allow_big_lds(k_color_bwd, LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_bwd, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_deform_bwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_bwd, DBWD_LDS_BYTES)) return e;
         attr_done = true;
     }
     if (src.M <= 0) return ST_OK;
@@ -471,7 +472,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
-    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), DBWD_LDS_BYTES, st, a); }
     return hip_last("point_backward_chains");
 }
 

@@ -30,14 +30,15 @@ __device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws +
 
 // -------------------------------------------------------------------------------------------------------------
 // deformation network, value + 3 tangents.  Tile = 16 points = 64 rows (row 4p + c).
-__global__ __launch_bounds__(NTHREADS) void k_deform_fwd(FwdArgs a) {
+// Two workgroups per CU (lean LDS carve, <= 256 registers): one workgroup's epilogue/barrier phases hide under the other's MFMAs.
+__global__ __launch_bounds__(NTHREADS, 2) void k_deform_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* scr = aux + AUX56_FLOATS;
     float* px = scr;         // [3][16]
     float* pt = scr + 48;    // [16]
-    float* red = scr + 64;   // [4][3][64]
+    float* red = aux;        // [4][3][64]: the encoding rows are dead after layer 3's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt0 = blockIdx.x * 16;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_deform_fwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_fwd, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd, LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd, LDS_BYTES)) return e;
         attr_done = true;
@@ -409,7 +410,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.L = ws_layout(src.M, flags); a.flags = flags;
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
-    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_forward");

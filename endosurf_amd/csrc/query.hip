@@ -15,15 +15,15 @@ namespace es {
 // its 64-row layout but only row-tile 0 carries points, so every layer issues half the MFMAs and twice as many workgroups
 // share the batch.
 template <bool DEFORM, bool HALF>
-__global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, const float4* __restrict__ packed,
+__global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb, const float4* __restrict__ packed,
                                                         const float* __restrict__ weff, float* __restrict__ sdf_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* scr = aux + AUX56_FLOATS;
     float* px = scr;          // [3][64]
     float* pt = scr + 192;    // [64]
-    float* red = scr + 256;   // [4][<=3][64]
+    float* red = aux;         // [4][<=3][64]: aliases the encoding rows, dead by the time the tiny last layers run
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int RTC = HALF ? 1 : 2;
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(NTHREADS) void k_query_sdf(PointSrc src, Tabs tb, c
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_query_sdf<true, false>, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf<false, false>, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf<true, true>, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf<false, true>, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<false, false>, LEAN_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<true, true>, LEAN_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf<false, true>, LEAN_LDS_BYTES)) return e;
         attr_done = true;
     }
     if (src.M <= 0) return ST_OK;
@@ -140,11 +140,11 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     const float4* pk = reinterpret_cast<const float4*>(packed);
     ScopedTimer tm(KID_QUERY, src.M, st);
     if (use_deform) {
-        if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
-        else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
     } else {
-        if (half) hipLaunchKernelGGL((k_query_sdf<false, true>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
-        else hipLaunchKernelGGL((k_query_sdf<false, false>), grid, block, LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        if (half) hipLaunchKernelGGL((k_query_sdf<false, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        else hipLaunchKernelGGL((k_query_sdf<false, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
     }
     return hip_last("query_sdf");
 }
