@@ -130,14 +130,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_deform_fwd(FwdArgs a) {
 
 // -------------------------------------------------------------------------------------------------------------
 // SDF network: value pass + reverse sweep.  Tile = 64 points.
-__global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void k_sdf_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* aux = lds + MAIN_FLOATS;        // 56 rows: enc6(x_c) (40 used), later the adjoint of the encoding (40 used)
+    float* scr = aux + AUX56_FLOATS;
     float* px = scr;          // [3][64]
-    float* red = scr + 256;   // [4][1][64]
-    float* gcv = scr + 512;   // [3][64]
+    float* red = aux;         // [4][1][64]  (encoding rows are dead when the last layer runs)
+    float* gcv = mainT;       // [3][64]     (activation tile is dead after the last reverse GEMM)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * TM;
@@ -232,8 +232,6 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
-        float spre[16][4];                                                                         // in flight during the GEMM
-        prefetch_quads<2, 2>(spre, Sl, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
@@ -244,21 +242,23 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_fwd(FwdArgs a) {
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
         }
         __syncthreads();
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4];
+            g_load_quad(Sl, grow0, 256, row, col, s);          // the co-resident workgroup's MFMAs cover this latency
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(spre[qi][i]);
+            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(s[i]);
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(RHO + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
         });
         if (l == 4)
-            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
         __syncthreads();
     }
     {
         f32x16 accA[1][1];
         acc_zero(accA);
         gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_add_quad(aux, col, row, v); });
     }
     __syncthreads();
     if (save) {
@@ -400,7 +400,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_deform_fwd, LEAN_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd, LDS_BYTES)) return e;
         attr_done = true;
     }
@@ -411,7 +411,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
-    { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
     return hip_last("point_forward");
 }
