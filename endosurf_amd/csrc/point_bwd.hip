@@ -197,11 +197,13 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
+// lean carve: activation tile | 40-row auxiliary tile | 640 floats of per-row data  => two workgroups per CU
+constexpr int SBWD_LDS_BYTES = (MAIN_FLOATS + 40 * TM + 640) * 4;   // 78 336 B
+__global__ __launch_bounds__(NTHREADS, 2) void k_sdf_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* scr = aux + 40 * TM;
     float* px = scr;           // [3][64] x_c
     float* gb = scr + 192;     // [3][64] gbar_c
     float* sb = scr + 384;     // [64] sdfbar
@@ -267,13 +269,16 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
     float* TAU = wsb(a, WS_S_TAU);
     float* ZB = wsb(a, WS_S_ZB);
     // ---- (i) forward tangent sweep ----
-    auto epi_t = [&](f32x16(&acc)[2][2], int l, float(&spre)[16][4], float(&rpre)[16][4]) {   // acc = pi_l
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            float z2[4];
+    // (epilogue operands are loaded in the epilogue: the co-resident workgroup's MFMAs cover the HBM latency)
+    auto epi_t = [&](f32x16(&acc)[2][2], int l) {   // acc = pi_l
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4], r[4], z2[4];
+            g_load_quad(SACT + (size_t)l * Mp * 256, grow0, 256, row, col, s);
+            g_load_quad(RHO + (size_t)l * Mp * 256, grow0, 256, row, col, r);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float dphi = softplus100_grad_from_s(spre[qi][i]);
-                z2[i] = 100.f * (1.f - dphi) * rpre[qi][i] * v[i];      // softplus'' / softplus' = 100 (1 - softplus')
+                const float dphi = softplus100_grad_from_s(s[i]);
+                z2[i] = 100.f * (1.f - dphi) * r[i] * v[i];             // softplus'' / softplus' = 100 (1 - softplus')
                 v[i] = dphi * v[i];                                     // tau_{l+1}
             }
             lds_store_quad(mainT, col, row, v);
@@ -282,34 +287,31 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
         });
     };
     {
-        float spre[16][4], rpre[16][4];
-        prefetch_quads<2, 2>(spre, SACT, grow0, 256, 0, 2 * wave, lane);
-        prefetch_quads<2, 2>(rpre, RHO, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
-        epi_t(acc, 0, spre, rpre);
+        epi_t(acc, 0);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
-        float spre[16][4], rpre[16][4];
-        prefetch_quads<2, 2>(spre, SACT + (size_t)l * Mp * 256, grow0, 256, 0, 2 * wave, lane);
-        prefetch_quads<2, 2>(rpre, RHO + (size_t)l * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
         __syncthreads();
-        epi_t(acc, l, spre, rpre);
+        epi_t(acc, l);
         __syncthreads();
     }
     // ---- (ii) reverse sweep of the value pass, seeded with zbar_8 = [sdfbar | featbar] ----
-    auto epi_b = [&](f32x16(&acc)[2][2], int l, float(&spre)[16][4], float(&zpre)[16][4]) {   // acc = sbar_l; zbar_{l-1} = phi'(z_{l-1}) sbar_l + 2nd order
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+    auto epi_b = [&](f32x16(&acc)[2][2], int l) {   // acc = sbar_l; zbar_{l-1} = phi'(z_{l-1}) sbar_l + second-order term
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float s[4], z2[4];
+            g_load_quad(SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, s);
+            g_load_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, z2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(spre[qi][i]) * v[i] + zpre[qi][i];
+            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
             lds_store_quad(mainT, col, row, v);
             g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
         });
@@ -342,9 +344,6 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
     for (int l = 7; l >= 1; --l) {
         f32x16 acc[2][2];
         acc_zero(acc);
-        float spre[16][4], zpre[16][4];
-        prefetch_quads<2, 2>(spre, SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
-        prefetch_quads<2, 2>(zpre, ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         f32x16 accA[1][1];
@@ -353,16 +352,16 @@ __global__ __launch_bounds__(NTHREADS) void k_sdf_bwd(BwdArgs a) {
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);
         }
         __syncthreads();
-        epi_b(acc, l, spre, zpre);
+        epi_b(acc, l);
         if (l == 4)
-            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
         __syncthreads();
     }
     {
         f32x16 accA[1][1];
         acc_zero(accA);
         gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_add_quad(aux, col, row, v); });
     }
     __syncthreads();
     if (tid < 192) {
@@ -460,7 +459,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_color_bwd, LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_bwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_bwd, SBWD_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_bwd, DBWD_LDS_BYTES)) return e;
         attr_done = true;
     }
@@ -471,7 +470,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
-    { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), SBWD_LDS_BYTES, st, a); }
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), DBWD_LDS_BYTES, st, a); }
     return hip_last("point_backward_chains");
 }
