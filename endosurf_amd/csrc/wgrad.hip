@@ -27,67 +27,75 @@ struct WgArgs {
     int nprob, total_tasks, MC;
 };
 
-// One workgroup (8 waves) = one task: a [256 x KW] tile of dW (all 256 output features x KW input features) over a
-// chunk of rows.  Both operand panels are staged through LDS in 16-row stages (double buffered, one barrier per stage), so
-// every dA / X element is read from HBM once per task instead of once per 64x64 wave tile.
-// wave w: n-block nb = w&3 (64 features, 2 MFMA tiles interleaved 2i+t), k-half kh = w>>2 (KTW tiles interleaved 2j+t').
-constexpr int WG_THREADS = 512;
+// One workgroup (4 waves) = one task: a [256 x 128] tile of dW (all 256 output features x 128 input features) over a chunk
+// of rows.  Both operand panels are staged through LDS in 16-row stages (double buffered, one barrier per stage, loads two
+// stages ahead), so every dA / X element is read from HBM once per task instead of once per 64x64 wave tile.  48 KB of LDS
+// and <= 256 registers => two workgroups per CU whose barrier phases interleave.
+// wave w: n-block w (64 features = 2 MFMA tiles interleaved 2i+t) x all 128 k (4 tiles: 64*jj + 2j+t').
+constexpr int WG_THREADS = 256;
 constexpr int WG_R = 16;                         // rows per stage
-constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + 256);
+constexpr int WG_KW = 128;                       // input features per task
+constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + WG_KW);
 
-template <int KTW>
 __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds) {
-    constexpr int KW = 64 * KTW;                 // input features per task
-    constexpr int BJ = KW / 128;                 // float4 loads of the X panel per thread per stage (KW=128 -> 1, 256 -> 2)
+    constexpr int KW = WG_KW;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = w & 3, kh = w >> 2;
+    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 31, hi = lane >> 5;
     auto Apan = [&](int buf) { return lds + buf * (WG_R * 256); };
     auto Bpan = [&](int buf) { return lds + 2 * WG_R * 256 + buf * (WG_R * KW); };
     const int kcol0 = kb * KW;
 
-    f32x16 acc[2][KTW];
+    f32x16 acc[2][4];
     acc_zero(acc);
     float bs0 = 0.f, bs1 = 0.f;
-    const bool do_bias = P.bias_out != nullptr && kb == 0 && kh == 0;
+    const bool do_bias = P.bias_out != nullptr && kb == 0;
 
-    // global -> register loads of one 16-row stage (two stages are kept in flight: sets 0/1), register -> LDS stores.
+    // global -> register loads of one 16-row stage (two stages in flight: sets 0/1), register -> LDS stores.
     // Plain ext-vector locals (not HIP float4 structs) so that they stay in VGPRs.
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f vzero = {0.f, 0.f, 0.f, 0.f};
-    const int fa0 = tid, fa1 = tid + WG_THREADS;
-    const size_t offA0 = (size_t)(fa0 >> 6) * P.lda + 4 * (fa0 & 63), offA1 = (size_t)(fa1 >> 6) * P.lda + 4 * (fa1 & 63);
-    const int colB0 = kcol0 + 4 * (fa0 % (KW / 4)), colB1 = kcol0 + 4 * (fa1 % (KW / 4));
-    const size_t offB0 = (size_t)(fa0 / (KW / 4)) * P.ldx + colB0, offB1 = (size_t)(fa1 / (KW / 4)) * P.ldx + colB1;
-    const bool okB0 = colB0 < P.ldx, okB1 = colB1 < P.ldx;
-#define WG_GLOAD(A0, A1, B0, B1, m)                                                                   \
+    size_t offA[4], offB[2];
+    bool okB[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = tid + WG_THREADS * j; offA[j] = (size_t)(f >> 6) * P.lda + 4 * (f & 63); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + WG_THREADS * j, col = kcol0 + 4 * (f % (KW / 4));
+        offB[j] = (size_t)(f / (KW / 4)) * P.ldx + col;
+        okB[j] = col < P.ldx;
+    }
+#define WG_GLOAD(S, m)                                                                                \
     {                                                                                                 \
         const float* pa = P.dA + (size_t)(m) * P.lda;                                                 \
         const float* pb = P.X + (size_t)(m) * P.ldx;                                                  \
-        A0 = *reinterpret_cast<const v4f*>(pa + offA0);                                               \
-        A1 = *reinterpret_cast<const v4f*>(pa + offA1);                                               \
-        B0 = okB0 ? *reinterpret_cast<const v4f*>(pb + offB0) : vzero;                                \
-        if (BJ == 2) B1 = okB1 ? *reinterpret_cast<const v4f*>(pb + offB1) : vzero;                   \
+        S##a0 = *reinterpret_cast<const v4f*>(pa + offA[0]);                                          \
+        S##a1 = *reinterpret_cast<const v4f*>(pa + offA[1]);                                          \
+        S##a2 = *reinterpret_cast<const v4f*>(pa + offA[2]);                                          \
+        S##a3 = *reinterpret_cast<const v4f*>(pa + offA[3]);                                          \
+        S##b0 = okB[0] ? *reinterpret_cast<const v4f*>(pb + offB[0]) : vzero;                         \
+        S##b1 = okB[1] ? *reinterpret_cast<const v4f*>(pb + offB[1]) : vzero;                         \
     }
-#define WG_SSTORE(A0, A1, B0, B1, buf)                                                                \
+#define WG_SSTORE(S, buf)                                                                             \
     {                                                                                                 \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa0) = A0;                                            \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = A1;                                            \
-        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * fa0) = B0;                                            \
-        if (BJ == 2) *reinterpret_cast<v4f*>(Bpan(buf) + 4 * fa1) = B1;                               \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                         \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + WG_THREADS)) = S##a1;                          \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + 2 * WG_THREADS)) = S##a2;                      \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + 3 * WG_THREADS)) = S##a3;                      \
+        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * tid) = S##b0;                                         \
+        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * (tid + WG_THREADS)) = S##b1;                          \
     }
     auto compute = [&](int buf, int m) {
         const float* A = Apan(buf) + nb * 64 + 2 * lo;
-        const float* B = Bpan(buf) + kh * (KW / 2) + 2 * lo;
+        const float* B = Bpan(buf) + 2 * lo;
 #pragma unroll
         for (int s = 0; s < WG_R / 2; ++s) {
             const float2 av = *reinterpret_cast<const float2*>(A + (2 * s + hi) * 256);
-            float2 bv[KTW / 2];
+            float2 bv[2];
 #pragma unroll
-            for (int jj = 0; jj < KTW / 2; ++jj) bv[jj] = *reinterpret_cast<const float2*>(B + (2 * s + hi) * KW + jj * 64);
+            for (int jj = 0; jj < 2; ++jj) bv[jj] = *reinterpret_cast<const float2*>(B + (2 * s + hi) * KW + jj * 64);
 #pragma unroll
-            for (int jj = 0; jj < KTW / 2; ++jj) {
+            for (int jj = 0; jj < 2; ++jj) {
                 acc[0][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].x, acc[0][2 * jj], 0, 0, 0);
                 acc[0][2 * jj + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].y, acc[0][2 * jj + 1], 0, 0, 0);
                 acc[1][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jj].x, acc[1][2 * jj], 0, 0, 0);
@@ -100,38 +108,34 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     // software pipeline: stage st computes from LDS[st&1] while the loads of stages st+1 (landing) and st+2 (just issued)
     // are in flight; one barrier per stage.  nst is even (chunks are multiples of 64 rows).
     const int nst = (m1 - m0) / WG_R;
-    v4f p0a0, p0a1, p0b0, p0b1 = vzero, p1a0, p1a1, p1b0, p1b1 = vzero;
-    WG_GLOAD(p0a0, p0a1, p0b0, p0b1, m0);
-    WG_GLOAD(p1a0, p1a1, p1b0, p1b1, m0 + WG_R);
-    WG_SSTORE(p0a0, p0a1, p0b0, p0b1, 0);
+    v4f p0a0, p0a1, p0a2, p0a3, p0b0, p0b1, p1a0, p1a1, p1a2, p1a3, p1b0, p1b1;
+    WG_GLOAD(p0, m0);
+    WG_GLOAD(p1, m0 + WG_R);
+    WG_SSTORE(p0, 0);
     __syncthreads();
 #pragma unroll 1
     for (int st = 0; st < nst; st += 2) {
-        if (st + 2 < nst) WG_GLOAD(p0a0, p0a1, p0b0, p0b1, m0 + WG_R * (st + 2));
+        if (st + 2 < nst) WG_GLOAD(p0, m0 + WG_R * (st + 2));
         compute(0, m0 + WG_R * st);
-        WG_SSTORE(p1a0, p1a1, p1b0, p1b1, 1);            // stage st+1 (loaded one iteration ago)
+        WG_SSTORE(p1, 1);                                // stage st+1 (loaded one iteration ago)
         __syncthreads();
-        if (st + 3 < nst) WG_GLOAD(p1a0, p1a1, p1b0, p1b1, m0 + WG_R * (st + 3));
+        if (st + 3 < nst) WG_GLOAD(p1, m0 + WG_R * (st + 3));
         compute(1, m0 + WG_R * (st + 1));
-        if (st + 2 < nst) WG_SSTORE(p0a0, p0a1, p0b0, p0b1, 0);   // stage st+2
+        if (st + 2 < nst) WG_SSTORE(p0, 0);              // stage st+2
         __syncthreads();
     }
 #undef WG_GLOAD
 #undef WG_SSTORE
-    // acc[t][2jj+tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*KW + kh*KW/2 + jj*64 + 2*lo + tp
+    // acc[t][2jj+tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*128 + jj*64 + 2*lo + tp
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int jt = 0; jt < KTW; ++jt) {
-            const int k = kcol0 + kh * (KW / 2) + (jt >> 1) * 64 + 2 * lo + (jt & 1);
+        for (int jt = 0; jt < 4; ++jt) {
+            const int k = kcol0 + (jt >> 1) * 64 + 2 * lo + (jt & 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + t;
-#ifdef WG_NO_ATOMIC
-                if (n < P.N && k < P.K) P.out[(size_t)n * P.ldo + k] = acc[t][jt][r];
-#else
                 if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][jt][r]);
-#endif
             }
         }
     if (do_bias) {
@@ -145,7 +149,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int task = blockIdx.x;
     int pi = 0;
@@ -154,12 +158,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgArgs a) {
         if (task >= a.p[i].task_begin) pi = i;
     const WgProb& P = a.p[pi];
     const int local = task - P.task_begin;
-    const bool narrow = P.K <= 128;
-    const int kblk = narrow ? 1 : (P.K + 255) / 256;
+    const int kblk = (P.K + WG_KW - 1) / WG_KW;
     const int kb = local % kblk, mc = local / kblk;
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
-    if (narrow) wgrad_task<2>(P, kb, m0, m1, wlds);
-    else wgrad_task<4>(P, kb, m0, m1, wlds);
+    wgrad_task(P, kb, m0, m1, wlds);
 }
 
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256).
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X
         for (int n = 0; n < N; ++n) atomicAdd(bias_out + n, bs[n]);
 }
 
-static int wg_kblk(const WgProb& p) { return p.K <= 128 ? 1 : (p.K + 255) / 256; }
+static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
 
 static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipStream_t st) {
     static bool attr_done = false;
@@ -201,7 +203,7 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
     // rows per task: aim at ~2 tasks per CU per launch (each task owns a CU: 8 waves, 64 KB LDS)
     double work = 0;
     for (int i = 0; i < nprob; ++i) work += (double)probs[i].M * wg_kblk(probs[i]);
-    int MC = (int)(work / 640.0);
+    int MC = (int)(work / 1536.0);       // ~3 tasks per workgroup slot (2 slots per CU)
     MC = (MC + 63) / 64 * 64;
     if (MC < 128) MC = 128;
     if (MC > 8192) MC = 8192;
