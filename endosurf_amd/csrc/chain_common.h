@@ -199,16 +199,20 @@ __device__ __forceinline__ void g_load_quad(const float* __restrict__ base, size
     v[0] = p[0]; v[1] = p[ld]; v[2] = p[2 * ld]; v[3] = p[3 * ld];
 }
 
-// Load a [64][256] row-major HBM tile into the k-major LDS tile (rows grow0.. of ``src`` with leading dim ld).
-__device__ __forceinline__ void load_tile_256(float* At, const float* __restrict__ src, size_t grow0, int ld, int tid) {
-    const int r = tid >> 2, c4 = tid & 3;          // 4 threads per row, 16 float4 each
+// Load a [64][NC] row-major HBM tile into rows 0..NC-1 of the k-major LDS tile (rows grow0.. of ``src``, leading dim ld).
+template <int NC>
+__device__ __forceinline__ void load_tile(float* At, const float* __restrict__ src, size_t grow0, int ld, int tid) {
+    const int r = tid >> 2, c4 = tid & 3;          // 4 threads per row, NC/16 float4 each
     const float* p = src + (grow0 + r) * (size_t)ld;
 #pragma unroll 4
-    for (int jj = 0; jj < 16; ++jj) {
+    for (int jj = 0; jj < NC / 16; ++jj) {
         const int c = 4 * (c4 + 4 * jj);
         const float4 v = *reinterpret_cast<const float4*>(p + c);
         At[swz(c + 0, r)] = v.x; At[swz(c + 1, r)] = v.y; At[swz(c + 2, r)] = v.z; At[swz(c + 3, r)] = v.w;
     }
+}
+__device__ __forceinline__ void load_tile_256(float* At, const float* __restrict__ src, size_t grow0, int ld, int tid) {
+    load_tile<256>(At, src, grow0, ld, tid);
 }
 
 // ---- activations ---------------------------------------------------------------------------------

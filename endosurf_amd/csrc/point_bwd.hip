@@ -45,12 +45,27 @@ __device__ __forceinline__ float enc3_adjoint(const float* At, int kbase, int j,
     return g;
 }
 
+// same contraction with the adjoint row in global memory (adj[idx], idx relative to the encoding's first element)
+template <int L>
+__device__ __forceinline__ float enc3_adjoint_g(const float* __restrict__ adj, int j, float x) {
+    float g = adj[j];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float f = (float)(1 << i);
+        float s, co;
+        sincosf(x * f, &s, &co);
+        g += f * (adj[enc_index(3, i, 0, j)] * co - adj[enc_index(3, i, 1, j)] * s);
+    }
+    return g;
+}
+
 // -------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
+// lean carve (activation tile + 3.75 KB): the adjoint of the input's small part accumulates in HBM (WS_C_SBAR), not in LDS
+constexpr int CBWD_LDS_BYTES = (MAIN_FLOATS + 960) * 4;   // 69 376 B
+__global__ __launch_bounds__(NTHREADS, 2) void k_color_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* scr = lds + MAIN_FLOATS;
     float* y8 = scr;           // [3][64]
     float* px = scr + 192;     // [3][64] x_c
     float* pd = scr + 384;     // [3][64] d_c
@@ -109,16 +124,20 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
         });
     }
     __syncthreads();
-    auto epi = [&](f32x16(&acc)[2][2], int l, float(&hpre)[16][4]) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
+    auto epi = [&](f32x16(&acc)[2][2], int l) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
+        const float* Hl = CH + (size_t)(l - 1) * Mp * 256;
         float* Yl = CY + (size_t)(l - 1) * Mp * 256;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float h[4];
+            g_load_quad(Hl, grow0, 256, row, col, h);          // latency covered by the co-resident workgroup
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = hpre[qi][i] > 0.f ? v[i] : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = h[i] > 0.f ? v[i] : 0.f;
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Yl, grow0, 256, row, col, v);
         });
     };
     float* FB = wsb(a, WS_FEATBAR);
+    float* SB = wsb(a, WS_C_SBAR);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         if (l == 4) {   // skip layer: adjoint also flows to the network input [small(93) | feat(256)]
@@ -132,17 +151,15 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
                 f32x16 accS[2][1];
                 acc_zero(accS);
                 gemm_seg<32, 2, 1>(accS, mainT, a.packed + a.tb.segoff[CR4S], 0, wave, lane);
-                for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { lds_store_quad(aux, col, row, v); });
+                for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { if (col < 96) g_store_quad(SB, grow0, 128, row, col, v); });
             }
         }
-        float hpre[16][4];                                                           // h_l, in flight during the GEMM
-        prefetch_quads<2, 2>(hpre, CH + (size_t)(l - 1) * Mp * 256, grow0, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l < 4 ? CR1 + (l - 1) : (l == 4 ? (int)CR4H : CR5 + (l - 5));
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l, hpre);
+        epi(acc, l);
         __syncthreads();
     }
     {   // layer 0: adjoint of the network input
@@ -159,13 +176,22 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
         f32x16 accS[2][1];
         acc_zero(accS);
         gemm_seg<32, 2, 1>(accS, mainT, a.packed + a.tb.segoff[CR0S], 0, wave, lane);
-        for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) { lds_add_quad(aux, col, row, v); });
+        for_quads(accS, 0, wave, lane, [&](int row, int col, float(&v)[4]) {
+            if (col < 96) {
+                float p[4];
+                g_load_quad(SB, grow0, 128, row, col, p);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += p[i];
+                g_store_quad(SB, grow0, 128, row, col, v);
+            }
+        });
     }
     __syncthreads();
     if (tid < 192) {
         const int j = tid >> 6, row = tid & 63;
-        tx[j * 64 + row] = enc3_adjoint<10>(aux, 0, j, row, px[j * 64 + row]);
-        td[j * 64 + row] = enc3_adjoint<4>(aux, 66, j, row, pd[j * 64 + row]);
+        const float* sbr = SB + (grow0 + row) * 128;
+        tx[j * 64 + row] = enc3_adjoint_g<10>(sbr, j, px[j * 64 + row]);
+        td[j * 64 + row] = enc3_adjoint_g<4>(sbr + 66, j, pd[j * 64 + row]);
     }
     __syncthreads();
     if (tid < 64) {
@@ -174,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void k_color_bwd(BwdArgs a) {
         float* gb = wsb(a, WS_GCBAR_C) + gp * 3;
         float* Jb = wsb(a, WS_JBAR_C) + gp * 9;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { xb[j] = tx[j * 64 + tid]; gb[j] = aux[swz(63 + j, tid)]; }
+        for (int j = 0; j < 3; ++j) { xb[j] = tx[j * 64 + tid]; gb[j] = SB[gp * 128 + 63 + j]; }
         if (deform) {   // d_c = v/(|v| + eps), v = J d  ->  vbar, Jbar = vbar d^T
             const float* J = wsb(a, WS_J) + gp * 9;
             float v[3], db[3] = {td[tid], td[64 + tid], td[128 + tid]};
@@ -458,7 +484,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_color_bwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_bwd, CBWD_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_bwd, SBWD_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_bwd, DBWD_LDS_BYTES)) return e;
         attr_done = true;
@@ -469,7 +495,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.L = ws_layout(src.M, flags); a.flags = flags; a.d_sdf = d_sdf; a.d_go = d_go; a.d_rgb = d_rgb;
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), CBWD_LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), SBWD_LDS_BYTES, st, a); }
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), DBWD_LDS_BYTES, st, a); }
     return hip_last("point_backward_chains");

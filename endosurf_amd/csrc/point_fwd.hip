@@ -298,12 +298,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sdf_fwd(FwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// colour network.  Tile = 64 points.
-__global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
+// colour network.  Tile = 64 points.  Lean LDS carve (activation tile + 5 KB): the 93-wide small part of the input is
+// staged through the activation tile itself (and re-staged from HBM at the skip layer), so two workgroups fit per CU.
+constexpr int CFWD_LDS_BYTES = (MAIN_FLOATS + 1344) * 4;   // 70 912 B
+__global__ __launch_bounds__(NTHREADS, 2) void k_color_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX_FLOATS;
+    float* scr = lds + MAIN_FLOATS;
     float* px = scr;          // [3][64] x_c
     float* pd = scr + 192;    // [3][64] d_c
     float* pg = scr + 384;    // [3][64] g_c
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
     const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM;
     const size_t Mp = (size_t)a.L.Mp;
     const float* feat = wsb(a, WS_FEAT);
+    float* CIN = wsb(a, WS_C_IN);
 
     if (tid < 64) {
         const size_t gp = grow0 + tid;
@@ -335,16 +337,15 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
         pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
     }
     __syncthreads();
-    encode3<10>(aux, 0, px, tid);       // rows 0..62
-    if (tid < 192) aux[swz(63 + (tid >> 6), tid & 63)] = pg[tid];
-    encode3<4>(aux, 66, pd, tid);       // rows 66..92
-    zero_rows(aux, 93, 96, tid);
-    load_tile_256(mainT, feat, grow0, 256, tid);
+    // small part [enc10(x_c) 63 | g_c 3 | enc4(d_c) 27 | 0 0 0] into rows 0..95 of the activation tile
+    encode3<10>(mainT, 0, px, tid);
+    if (tid < 192) mainT[swz(63 + (tid >> 6), tid & 63)] = pg[tid];
+    encode3<4>(mainT, 66, pd, tid);
+    zero_rows(mainT, 93, 96, tid);
     __syncthreads();
-    if (save) {
-        float* CIN = wsb(a, WS_C_IN);
+    {
         const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 96; k += 4) CIN[(grow0 + r) * 128 + k] = aux[swz(k, r)];
+        for (int k = c4; k < 96; k += 4) CIN[(grow0 + r) * 128 + k] = mainT[swz(k, r)];
     }
     float* CH = wsb(a, WS_C_H);
     auto epi = [&](f32x16(&acc)[2][2], int l) {
@@ -361,8 +362,11 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
     {
         f32x16 acc[2][2];
         acc_zero(acc);
+        gemm_seg<12, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0S], 0, 2 * wave, lane);
+        __syncthreads();
+        load_tile_256(mainT, feat, grow0, 256, tid);
+        __syncthreads();
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0F], 0, 2 * wave, lane);
-        gemm_seg<12, 2, 2>(acc, aux, a.packed + a.tb.segoff[CF0S], 0, 2 * wave, lane);
         __syncthreads();
         epi(acc, 0);
     }
@@ -374,13 +378,16 @@ __global__ __launch_bounds__(NTHREADS) void k_color_fwd(FwdArgs a) {
         if (l != 4) {
             const int seg = l < 4 ? CF1 + (l - 1) : CF5 + (l - 5);
             gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
-        } else {   // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
+        } else {   // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2, staged through the tile one part at a time
             gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4H], 0, 2 * wave, lane);
+            __syncthreads();
+            load_tile<96>(mainT, CIN, grow0, 128, tid);
+            __syncthreads();
+            gemm_seg<12, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4S], 0, 2 * wave, lane);
             __syncthreads();
             load_tile_256(mainT, feat, grow0, 256, tid);
             __syncthreads();
             gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4F], 0, 2 * wave, lane);
-            gemm_seg<12, 2, 2>(acc, aux, a.packed + a.tb.segoff[CF4S], 0, 2 * wave, lane);
         }
         __syncthreads();
         epi(acc, l);
@@ -401,7 +408,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     if (!attr_done) {
         if (int e = allow_big_lds(k_deform_fwd, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd, LEAN_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_color_fwd, LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd, CFWD_LDS_BYTES)) return e;
         attr_done = true;
     }
     if (src.M <= 0) return ST_OK;
@@ -412,7 +419,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), LDS_BYTES, st, a); }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), CFWD_LDS_BYTES, st, a); }
     return hip_last("point_forward");
 }
 

@@ -164,30 +164,36 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgArgs a) {
     wgrad_task(P, kb, m0, m1, wlds);
 }
 
-// tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256).
+// tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256), 32 rows per block:
+// the adjoint rows go through LDS once, then all 32 row loads of X are in flight together (pure HBM stream over X).
 // dA == nullptr means dA = 1 (column sums of X).
+constexpr int WS_ROWS = 32;
 __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X, int ldx, const float* __restrict__ dA, int lda, int M, int K,
-                                                     int N, float* __restrict__ out, int ldo, float* __restrict__ bias_out, int bias_stride,
-                                                     int MC) {
+                                                     int N, float* __restrict__ out, int ldo, float* __restrict__ bias_out, int bias_stride) {
+    __shared__ float sd[WS_ROWS][4];
     const int k = threadIdx.x;
-    const int m0 = blockIdx.x * MC, m1 = min(m0 + MC, M);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int m = m0; m < m1; ++m) {
-        const float x = k < K ? X[(size_t)m * ldx + k] : 0.f;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (n < N) {
-                const float d = dA ? dA[(size_t)m * lda + n] : 1.f;
-                acc[n] = fmaf(d, x, acc[n]);
-                if ((m % bias_stride) == 0) bs[n] += d;
-            }
-        }
+    const int m0 = blockIdx.x * WS_ROWS;
+    if (k < WS_ROWS * 4) {
+        const int r = k >> 2, n = k & 3;
+        sd[r][n] = (m0 + r < M && n < N) ? (dA ? dA[(size_t)(m0 + r) * lda + n] : 1.f) : 0.f;
     }
+    float x[WS_ROWS];
+#pragma unroll
+    for (int r = 0; r < WS_ROWS; ++r) x[r] = (k < K && m0 + r < M) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < WS_ROWS; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = fmaf(sd[r][n], x[r], acc[n]);
     if (k < K)
         for (int n = 0; n < N; ++n) atomicAdd(out + (size_t)n * ldo + k, acc[n]);
-    if (bias_out && k == 0)
-        for (int n = 0; n < N; ++n) atomicAdd(bias_out + n, bs[n]);
+    if (bias_out && k < N) {
+        float bsum = 0.f;
+        for (int r = 0; r < WS_ROWS; ++r)
+            if (((m0 + r) % bias_stride) == 0) bsum += sd[r][k];
+        atomicAdd(bias_out + k, bsum);
+    }
 }
 
 static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
@@ -222,11 +228,8 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
 }
 static void launch_small(const float* X, int ldx, const float* dA, int lda, int M, int K, int N, float* out, int ldo, float* bias_out,
                          int bias_stride, hipStream_t st) {
-    int MC = (M + 4095) / 4096;        // up to 4096 blocks: the kernel is a pure stream over X
-    MC = (MC + 31) / 32 * 32;
-    if (MC < 32) MC = 32;
     ScopedTimer tm(KID_WGRAD_SMALL, M, st);
-    hipLaunchKernelGGL(k_wgrad_small, dim3((M + MC - 1) / MC), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride, MC);
+    hipLaunchKernelGGL(k_wgrad_small, dim3((M + WS_ROWS - 1) / WS_ROWS), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride);
 }
 
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).

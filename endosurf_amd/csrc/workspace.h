@@ -36,6 +36,7 @@ enum WsBuf : int {
     WS_XCBAR, WS_JBAR,
     WS_D_A,        // [8][4Mp][256] adjoints of deform pre-activations a_0..7
     WS_D_A8,       // [4Mp][4]
+    WS_C_SBAR,     // [Mp][128]     adjoint of the colour input's small part (93 valid)
     WS_COUNT
 };
 
@@ -54,6 +55,7 @@ inline WsLayout ws_layout(int M, int flags) {
     size_t sz[WS_COUNT] = {0};
     sz[WS_XC] = Mp * 3; sz[WS_J] = Mp * 9; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
     sz[WS_FEAT] = col ? Mp * 256 : 0; sz[WS_RGB] = col ? Mp * 3 : 0;
+    sz[WS_C_IN] = col ? Mp * 128 : 0;      // always: the colour kernel re-stages it at the skip layer
     sz[WS_S_ACT] = 8 * Mp * 256;
     if (save) {
         if (def) { sz[WS_D_U0] = 4 * Mp * 64; sz[WS_D_U] = 8 * 4 * Mp * 256; sz[WS_D_A] = 8 * 4 * Mp * 256; sz[WS_D_A8] = 4 * Mp * 4; }
@@ -61,7 +63,7 @@ inline WsLayout ws_layout(int M, int flags) {
         sz[WS_S_TAU0] = Mp * 64; sz[WS_S_TAU] = 8 * Mp * 256; sz[WS_S_ZB] = 8 * Mp * 256;
         sz[WS_XCBAR] = Mp * 3; sz[WS_JBAR] = Mp * 9;
         if (col) {
-            sz[WS_C_IN] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
+            sz[WS_C_SBAR] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
             sz[WS_FEATBAR] = Mp * 256; sz[WS_XCBAR_C] = Mp * 3; sz[WS_GCBAR_C] = Mp * 3; sz[WS_JBAR_C] = Mp * 9;
         }
     }
