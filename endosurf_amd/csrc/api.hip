@@ -94,7 +94,7 @@ int es_weff_layout(int net, int layer, int64_t* w_off, int64_t* b_off) {
         }
     return ST_BAD_ARG;
 }
-int64_t es_packed_floats(void) { return (int64_t)PACKED_FLOATS; }
+int64_t es_packed_floats(void) { return (int64_t)PACKED_TOTAL_FLOATS; }
 
 int es_weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, void* stream) {
     ES_REQUIRE(params && weff && packed, "null buffer");

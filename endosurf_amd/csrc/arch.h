@@ -162,6 +162,19 @@ constexpr size_t seg_off4(int id) {
 constexpr size_t PACKED_FLOAT4 = seg_off4(SEG_COUNT);
 constexpr size_t PACKED_FLOATS = PACKED_FLOAT4 * 4;
 
+// ---- second packing of the forward query segments for v_mfma_f32_16x16x4_f32 (16-point tiles of the latency-bound
+// small-batch SDF query): float4 tiles [nt16][g][lane], element j of lane l = B[16g + 4j + (l>>4)][16 nt16 + (l&15)].
+constexpr int P16_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7};
+constexpr int P16_COUNT = sizeof(P16_SEGS) / sizeof(int);
+constexpr int p16_kg(int i) { return cdiv(SEGS[P16_SEGS[i]].kreal, 16); }
+constexpr size_t p16_off4(int i) {     // float4 offset inside the packed buffer (after the 32x32 segments)
+    size_t off = PACKED_FLOAT4;
+    for (int k = 0; k < i; ++k) off += (size_t)p16_kg(k) * 16 * 64;
+    return off;
+}
+constexpr size_t PACKED_TOTAL_FLOAT4 = p16_off4(P16_COUNT);
+constexpr size_t PACKED_TOTAL_FLOATS = PACKED_TOTAL_FLOAT4 * 4;
+
 constexpr float INV_SQRT2 = 0.70710678118654752440f;
 
 }  // namespace es

@@ -17,6 +17,8 @@ __constant__ int c_layer_k[NETS * LAYERS];
 __constant__ int c_layer_n[NETS * LAYERS];
 __constant__ int c_param_off[NETS * LAYERS];
 __constant__ int c_weff_off[NETS * LAYERS];
+__constant__ int c_p16_segs[P16_COUNT];
+#define P16_SEGS_DEV(i) c_p16_segs[i]
 
 static bool g_tables_ready = false;
 
@@ -45,6 +47,7 @@ int init_tables() {
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_layer_n), ln, sizeof(ln)));
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_param_off), po, sizeof(po)));
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_weff_off), wo, sizeof(wo)));
+    ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_p16_segs), P16_SEGS, sizeof(P16_SEGS)));
     g_tables_ready = true;
     return 0;
 }
@@ -135,6 +138,39 @@ __global__ __launch_bounds__(256) void k_weightnorm_bwd(const float* __restrict_
     if (lane == 0) { og[n] = dg; ob[n] = dweff[c_weff_off[li] + (size_t)N * K + n]; }
 }
 
+// one thread per float4 of the 16x16x4 packing (forward query segments only)
+__global__ __launch_bounds__(256) void k_pack16(const float* __restrict__ weff, float4* __restrict__ packed, int first_net) {
+    const unsigned long long idx = PACKED_FLOAT4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PACKED_TOTAL_FLOAT4) return;
+    int pi = 0;
+    unsigned long long base = PACKED_FLOAT4, off = PACKED_FLOAT4;
+#pragma unroll 1
+    for (int i = 0; i < P16_COUNT; ++i) {
+        const unsigned long long sz = (unsigned long long)((c_segs[P16_SEGS_DEV(i)].kreal + 15) / 16) * 16 * 64;
+        if (idx >= off) { pi = i; base = off; }
+        off += sz;
+    }
+    const SegDev sd = c_segs[P16_SEGS_DEV(pi)];
+    if (sd.net < first_net) return;
+    const int kg = (sd.kreal + 15) / 16;
+    const unsigned rel = (unsigned)(idx - base);
+    const int lane = rel & 63;
+    const int g = (rel >> 6) % kg;
+    const int nt = (rel >> 6) / kg;
+    const int li = sd.net * LAYERS + sd.layer;
+    const int K = c_layer_k[li];
+    const float* W = weff + c_weff_off[li];
+    const float sc = sd.skip_scale ? INV_SQRT2 : 1.f;
+    const int n = 16 * nt + (lane & 15);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 16 * g + 4 * j + (lane >> 4);
+        o[j] = (k < sd.kreal && n < sd.nreal) ? sc * W[(size_t)(sd.row0 + n) * K + sd.col0 + k] : 0.f;   // forward orientation only
+    }
+    packed[idx] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st) {
     if (int e = init_tables()) return e;
     const int first_layer = use_deform ? 0 : LAYERS;
@@ -142,6 +178,8 @@ int weightnorm_pack(const float* params, float* weff, float* packed, int use_def
     hipLaunchKernelGGL(k_weff, g1, dim3(256), 0, st, params, weff, first_layer);
     const unsigned nb = (unsigned)((PACKED_FLOAT4 + 255) / 256);
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, (const float*)weff, reinterpret_cast<float4*>(packed), use_deform ? 0 : 1);
+    const unsigned nb16 = (unsigned)((PACKED_TOTAL_FLOAT4 - PACKED_FLOAT4 + 255) / 256);
+    hipLaunchKernelGGL(k_pack16, dim3(nb16), dim3(256), 0, st, (const float*)weff, reinterpret_cast<float4*>(packed), use_deform ? 0 : 1);
     return hip_last("weightnorm_pack");
 }
 

@@ -123,7 +123,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     if (tid < PTS && row0 + tid < src.M) sdf_out[row0 + tid] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
 }
 
+int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
+
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
+    if (src.M > 0 && src.M <= 8192) return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;

@@ -1,0 +1,227 @@
+// Small-batch variant of K2 (sdf(x + deform(x,t)), no grad): 16-point tiles on v_mfma_f32_16x16x4_f32.
+// The secant iterations of ray marching (1024 points, 8 dependent launches) and the 8-sample up-sampling queries are
+// latency-bound: a workgroup's time per layer is fixed by its tile height (a 32-row tile keeps one CU's matrix pipes busy
+// for 16 384 cycles per 256x256 layer however many waves share it), so small batches want SHORT tiles and many
+// workgroups.  16 rows x 256 columns per workgroup = 8 192 cycles per layer, 4x more workgroups than the 64-point kernel.
+// Weights come from the 16x16x4 packing appended to the packed buffer (arch.h P16_SEGS).
+#include "chain_common.h"
+#include "launch.h"
+#include "tabs.h"
+#include "timing.h"
+
+namespace es {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int T16 = 16;
+constexpr int Q16_MAIN = HID * T16;          // 16 KiB activation tile [k][16 rows]
+constexpr int Q16_AUX = 64 * T16;            // encodings (<= 64 rows incl. padding to the 16-k groups)
+constexpr int Q16_LDS_BYTES = (Q16_MAIN + Q16_AUX + 1024) * 4;
+
+// element (k, row) of a 16-row k-major tile; the XOR keeps ds_write_b128 epilogue stores and the A-fragment reads conflict-free
+__device__ __forceinline__ int swz16(int k, int r) { return k * T16 + (r ^ (((k >> 1) & 3) << 2)); }
+
+// acc[ni] += A[16 rows][0 .. 16*KG) * B[..][16 cols of n-tile nt0+ni], ni < 4 (this wave's 64 columns)
+template <int KG>
+__device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const float4* __restrict__ W, int nt0, int lane) {
+    const int lo = lane & 15, hi = lane >> 4;
+    const float4* wl = W + lane;
+    float4 b0[4], b1[4];
+    auto loadB = [&](float4(&b)[4], int g) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = wl[(size_t)((nt0 + ni) * KG + g) * 64];
+    };
+    auto comp = [&](const float4(&b)[4], int g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = At[swz16(16 * g + 4 * j + hi, lo)];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(b[ni], j), acc[ni], 0, 0, 0);
+        }
+    };
+    loadB(b0, 0);
+#pragma unroll 1
+    for (int g = 0; g < KG; g += 2) {
+        if (g + 1 < KG) loadB(b1, g + 1);
+        comp(b0, g);
+        if (g + 2 < KG) loadB(b0, g + 2);
+        if (g + 1 < KG) comp(b1, g + 1);
+    }
+}
+
+// C/D layout of the 16x16 MFMA: col = lane&15, rows 4*(lane>>4) + reg: one quad of 4 consecutive rows per (lane, n-tile)
+template <class F>
+__device__ __forceinline__ void epi16(f32x4v (&acc)[4], float* mainT, int nt0, int lane, F&& f) {
+    const int lo = lane & 15, rb = 4 * (lane >> 4);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = (nt0 + ni) * 16 + lo;
+        float v[4] = {acc[ni][0], acc[ni][1], acc[ni][2], acc[ni][3]};
+        f(col, rb, v);
+        *reinterpret_cast<float4*>(&mainT[swz16(col, rb)]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int NOUT>
+__device__ __forceinline__ void smalln16(const float* At, const float* __restrict__ Wrows, int ldw, float* red, int tid) {
+    // 256 threads: row = tid & 15, k-part = tid >> 4 (16 parts of 16 k)
+    const int row = tid & 15, part = tid >> 4;
+    float s[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = part * 16 + kk;
+        const float a = At[swz16(k, row)];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) s[i] = fmaf(Wrows[i * ldw + k], a, s[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) red[(part * NOUT + i) * 16 + row] = s[i];
+}
+template <int NOUT>
+__device__ __forceinline__ float smalln16_reduce(const float* red, int i, int row) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s += red[(p * NOUT + i) * 16 + row];
+    return s;
+}
+
+template <int L>
+__device__ __forceinline__ void encode3_16(float* At, int kbase, const float* px, int tid) {   // px[c*16 + row]
+    const int row = tid & 15;
+    for (int item = tid >> 4; item < 3 * L; item += 16) {
+        const int c = item % 3, i = item / 3;
+        float s, co;
+        sincosf(px[c * 16 + row] * (float)(1 << i), &s, &co);
+        At[swz16(kbase + enc_index(3, i, 0, c), row)] = s;
+        At[swz16(kbase + enc_index(3, i, 1, c), row)] = co;
+    }
+    if (tid < 48) At[swz16(kbase + (tid >> 4), row)] = px[(tid >> 4) * 16 + row];
+}
+
+template <bool DEFORM>
+__global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs tb, const float4* __restrict__ packed,
+                                                             const float* __restrict__ weff, float* __restrict__ sdf_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + Q16_MAIN;
+    float* scr = aux + Q16_AUX;
+    float* px = scr;          // [3][16]
+    float* pt = scr + 48;     // [16]
+    float* red = scr + 64;    // [16][<=3][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * T16;
+    const int nt0 = 4 * wave;
+
+    if (tid < 16) {
+        float x[3], t, d[3];
+        load_point(src, row0 + tid, x, t, d);
+        px[tid] = x[0]; px[16 + tid] = x[1]; px[32 + tid] = x[2]; pt[tid] = t;
+    }
+    for (int i = tid; i < Q16_AUX; i += NTHREADS) aux[i] = 0.f;          // zero padding rows (k up to 64)
+    __syncthreads();
+    auto relu_epi = [&](f32x4v(&acc)[4], const float* bias) {
+        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+        });
+    };
+    auto zero4 = [&](f32x4v(&acc)[4]) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
+    if (DEFORM) {
+        encode3_16<6>(aux, 0, px, tid);
+        {   // time encoding rows 39..51
+            const int row = tid & 15;
+            for (int i = tid >> 4; i < 6; i += 16) {
+                float s, co;
+                sincosf(pt[row] * (float)(1 << i), &s, &co);
+                aux[swz16(39 + enc_index(1, i, 0, 0), row)] = s;
+                aux[swz16(39 + enc_index(1, i, 1, 0), row)] = co;
+            }
+            if (tid < 16) aux[swz16(39, row)] = pt[row];
+        }
+        __syncthreads();
+        {
+            f32x4v acc[4];
+            zero4(acc);
+            gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane);
+            relu_epi(acc, weff + tb.boff[NET_D * LAYERS + 0]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            f32x4v acc[4];
+            zero4(acc);
+            gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane);
+            __syncthreads();
+            const float* bias = weff + tb.boff[NET_D * LAYERS + l];
+            epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
+                if (l == 3 && col >= 204) {                                  // IDR skip: [h(204) | enc(52)]
+                    const float4 e = *reinterpret_cast<const float4*>(&aux[swz16(col - 204, rb)]);
+                    v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
+                } else {
+                    const float b = bias[col];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+                }
+            });
+            __syncthreads();
+        }
+        smalln16<3>(mainT, weff + tb.woff[NET_D * LAYERS + 8], 256, red, tid);
+        __syncthreads();
+        if (tid < 48) {
+            const int i = tid >> 4, row = tid & 15;
+            px[i * 16 + row] += smalln16_reduce<3>(red, i, row) + weff[tb.boff[NET_D * LAYERS + 8] + i];
+        }
+        __syncthreads();
+        for (int i = tid; i < Q16_AUX; i += NTHREADS) aux[i] = 0.f;
+        __syncthreads();
+    }
+    encode3_16<6>(aux, 0, px, tid);
+    __syncthreads();
+    auto sp_epi = [&](f32x4v(&acc)[4], const float* bias) {
+        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
+            const float b = bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
+        });
+    };
+    {
+        f32x4v acc[4];
+        zero4(acc);
+        gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane);
+        sp_epi(acc, weff + tb.boff[NET_S * LAYERS + 0]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x4v acc[4];
+        zero4(acc);
+        const int pi = l <= 4 ? 8 + l : 8 + l + 1;          // P16_SEGS order: SF0..SF3, SF4M, SF4A, SF5..SF7
+        gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane);
+        if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane);
+        __syncthreads();
+        sp_epi(acc, weff + tb.boff[NET_S * LAYERS + l]);
+        __syncthreads();
+    }
+    smalln16<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 16 && row0 + tid < src.M) sdf_out[row0 + tid] = smalln16_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+}
+
+int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
+    if (src.M <= 0) return ST_OK;
+    const Tabs tb = make_tabs();
+    const dim3 grid((src.M + T16 - 1) / T16), block(NTHREADS);
+    const float4* pk = reinterpret_cast<const float4*>(packed);
+    ScopedTimer tm(KID_QUERY, src.M, st);
+    if (use_deform) hipLaunchKernelGGL(k_query_sdf16<true>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+    else hipLaunchKernelGGL(k_query_sdf16<false>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+    return hip_last("query_sdf16");
+}
+
+}  // namespace es

@@ -9,6 +9,7 @@ struct Tabs {
     int boff[NETS * LAYERS];       // bias offset inside the effective-weight buffer
     int woff[NETS * LAYERS];       // weight offset inside the effective-weight buffer
     unsigned segoff[SEG_COUNT];    // float4 offset of each packed segment
+    unsigned p16off[P16_COUNT];    // float4 offset of each 16x16x4-packed query segment
 };
 
 inline Tabs make_tabs() {
@@ -25,6 +26,7 @@ inline Tabs make_tabs() {
         t.segoff[i] = (unsigned)off;
         off += (size_t)seg_kg(SEGS[i]) * seg_nt(SEGS[i]) * 64;
     }
+    for (int i = 0; i < P16_COUNT; ++i) t.p16off[i] = (unsigned)p16_off4(i);
     return t;
 }
 

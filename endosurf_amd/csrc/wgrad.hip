@@ -167,33 +167,39 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgArgs a) {
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256), 32 rows per block:
 // the adjoint rows go through LDS once, then all 32 row loads of X are in flight together (pure HBM stream over X).
 // dA == nullptr means dA = 1 (column sums of X).
-constexpr int WS_ROWS = 32;
+constexpr int WS_ROWS = 32;       // rows per inner step (all loads in flight together)
+constexpr int WS_STEPS = 16;      // steps per block: one set of atomics per 512 rows keeps same-address contention low
 __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X, int ldx, const float* __restrict__ dA, int lda, int M, int K,
                                                      int N, float* __restrict__ out, int ldo, float* __restrict__ bias_out, int bias_stride) {
-    __shared__ float sd[WS_ROWS][4];
+    __shared__ float sd[2][WS_ROWS][4];
     const int k = threadIdx.x;
-    const int m0 = blockIdx.x * WS_ROWS;
-    if (k < WS_ROWS * 4) {
-        const int r = k >> 2, n = k & 3;
-        sd[r][n] = (m0 + r < M && n < N) ? (dA ? dA[(size_t)(m0 + r) * lda + n] : 1.f) : 0.f;
-    }
-    float x[WS_ROWS];
-#pragma unroll
-    for (int r = 0; r < WS_ROWS; ++r) x[r] = (k < K && m0 + r < M) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
-    __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int mbase = blockIdx.x * (WS_ROWS * WS_STEPS);
+#pragma unroll 1
+    for (int it = 0; it < WS_STEPS; ++it) {
+        const int m0 = mbase + it * WS_ROWS;
+        if (m0 >= M) break;
+        float(&sdb)[WS_ROWS][4] = sd[it & 1];
+        if (k < WS_ROWS * 4) {
+            const int r = k >> 2, n = k & 3;
+            sdb[r][n] = (m0 + r < M && n < N) ? (dA ? dA[(size_t)(m0 + r) * lda + n] : 1.f) : 0.f;
+        }
+        float x[WS_ROWS];
 #pragma unroll
-    for (int r = 0; r < WS_ROWS; ++r)
+        for (int r = 0; r < WS_ROWS; ++r) x[r] = (k < K && m0 + r < M) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
+        __syncthreads();                                   // double-buffered sd: one barrier per step suffices
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = fmaf(sd[r][n], x[r], acc[n]);
+        for (int r = 0; r < WS_ROWS; ++r)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = fmaf(sdb[r][n], x[r], acc[n]);
+        if (bias_out && k < N)
+            for (int r = 0; r < WS_ROWS; ++r)
+                if (((m0 + r) % bias_stride) == 0) bsum += sdb[r][k];
+    }
     if (k < K)
         for (int n = 0; n < N; ++n) atomicAdd(out + (size_t)n * ldo + k, acc[n]);
-    if (bias_out && k < N) {
-        float bsum = 0.f;
-        for (int r = 0; r < WS_ROWS; ++r)
-            if (((m0 + r) % bias_stride) == 0) bsum += sd[r][k];
-        atomicAdd(bias_out + k, bsum);
-    }
+    if (bias_out && k < N) atomicAdd(bias_out + k, bsum);
 }
 
 static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
@@ -229,7 +235,7 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
 static void launch_small(const float* X, int ldx, const float* dA, int lda, int M, int K, int N, float* out, int ldo, float* bias_out,
                          int bias_stride, hipStream_t st) {
     ScopedTimer tm(KID_WGRAD_SMALL, M, st);
-    hipLaunchKernelGGL(k_wgrad_small, dim3((M + WS_ROWS - 1) / WS_ROWS), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride);
+    hipLaunchKernelGGL(k_wgrad_small, dim3((M + WS_ROWS * WS_STEPS - 1) / (WS_ROWS * WS_STEPS)), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride);
 }
 
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
