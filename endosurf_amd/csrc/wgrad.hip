@@ -27,12 +27,12 @@ struct WgArgs {
     int nprob, total_tasks, MC;
 };
 
-// One workgroup (4 waves) = one task: a [256 x 128] tile of dW (all 256 output features x 128 input features) over a chunk
+// One workgroup (8 waves) = one task: a [256 x 128] tile of dW (all 256 output features x 128 input features) over a chunk
 // of rows.  Both operand panels are staged through LDS in 16-row stages (double buffered, one barrier per stage, loads two
 // stages ahead), so every dA / X element is read from HBM once per task instead of once per 64x64 wave tile.  48 KB of LDS
-// and <= 256 registers => two workgroups per CU whose barrier phases interleave.
-// wave w: n-block w (64 features = 2 MFMA tiles interleaved 2i+t) x all 128 k (4 tiles: 64*jj + 2j+t').
-constexpr int WG_THREADS = 256;
+// and <= 128 registers => two workgroups (16 waves) per CU whose barrier phases interleave.
+// wave w: n-block w&3 (64 features = 2 MFMA tiles interleaved 2i+t) x k-half w>>2 (64 features = 2 tiles interleaved 2j+t').
+constexpr int WG_THREADS = 512;
 constexpr int WG_R = 16;                         // rows per stage
 constexpr int WG_KW = 128;                       // input features per task
 constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + WG_KW);
@@ -40,67 +40,51 @@ constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + WG_KW);
 __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds) {
     constexpr int KW = WG_KW;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = w & 3, kh = w >> 2;
     const int lo = lane & 31, hi = lane >> 5;
     auto Apan = [&](int buf) { return lds + buf * (WG_R * 256); };
     auto Bpan = [&](int buf) { return lds + 2 * WG_R * 256 + buf * (WG_R * KW); };
     const int kcol0 = kb * KW;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][2];
     acc_zero(acc);
     float bs0 = 0.f, bs1 = 0.f;
-    const bool do_bias = P.bias_out != nullptr && kb == 0;
+    const bool do_bias = P.bias_out != nullptr && kb == 0 && kh == 0;
 
     // global -> register loads of one 16-row stage (two stages in flight: sets 0/1), register -> LDS stores.
     // Plain ext-vector locals (not HIP float4 structs) so that they stay in VGPRs.
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f vzero = {0.f, 0.f, 0.f, 0.f};
-    size_t offA[4], offB[2];
-    bool okB[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int f = tid + WG_THREADS * j; offA[j] = (size_t)(f >> 6) * P.lda + 4 * (f & 63); }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int f = tid + WG_THREADS * j, col = kcol0 + 4 * (f % (KW / 4));
-        offB[j] = (size_t)(f / (KW / 4)) * P.ldx + col;
-        okB[j] = col < P.ldx;
-    }
+    const int fa1 = tid + WG_THREADS;
+    const size_t offA0 = (size_t)(tid >> 6) * P.lda + 4 * (tid & 63), offA1 = (size_t)(fa1 >> 6) * P.lda + 4 * (fa1 & 63);
+    const int colB = kcol0 + 4 * (tid % (KW / 4));
+    const size_t offB = (size_t)(tid / (KW / 4)) * P.ldx + colB;
+    const bool okB = colB < P.ldx;
 #define WG_GLOAD(S, m)                                                                                \
     {                                                                                                 \
         const float* pa = P.dA + (size_t)(m) * P.lda;                                                 \
-        const float* pb = P.X + (size_t)(m) * P.ldx;                                                  \
-        S##a0 = *reinterpret_cast<const v4f*>(pa + offA[0]);                                          \
-        S##a1 = *reinterpret_cast<const v4f*>(pa + offA[1]);                                          \
-        S##a2 = *reinterpret_cast<const v4f*>(pa + offA[2]);                                          \
-        S##a3 = *reinterpret_cast<const v4f*>(pa + offA[3]);                                          \
-        S##b0 = okB[0] ? *reinterpret_cast<const v4f*>(pb + offB[0]) : vzero;                         \
-        S##b1 = okB[1] ? *reinterpret_cast<const v4f*>(pb + offB[1]) : vzero;                         \
+        S##a0 = *reinterpret_cast<const v4f*>(pa + offA0);                                            \
+        S##a1 = *reinterpret_cast<const v4f*>(pa + offA1);                                            \
+        S##b0 = okB ? *reinterpret_cast<const v4f*>(P.X + (size_t)(m) * P.ldx + offB) : vzero;        \
     }
 #define WG_SSTORE(S, buf)                                                                             \
     {                                                                                                 \
         *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                         \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + WG_THREADS)) = S##a1;                          \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + 2 * WG_THREADS)) = S##a2;                      \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * (tid + 3 * WG_THREADS)) = S##a3;                      \
+        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = S##a1;                                         \
         *reinterpret_cast<v4f*>(Bpan(buf) + 4 * tid) = S##b0;                                         \
-        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * (tid + WG_THREADS)) = S##b1;                          \
     }
     auto compute = [&](int buf, int m) {
         const float* A = Apan(buf) + nb * 64 + 2 * lo;
-        const float* B = Bpan(buf) + 2 * lo;
+        const float* B = Bpan(buf) + kh * 64 + 2 * lo;
 #pragma unroll
         for (int s = 0; s < WG_R / 2; ++s) {
             const float2 av = *reinterpret_cast<const float2*>(A + (2 * s + hi) * 256);
-            float2 bv[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) bv[jj] = *reinterpret_cast<const float2*>(B + (2 * s + hi) * KW + jj * 64);
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                acc[0][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].x, acc[0][2 * jj], 0, 0, 0);
-                acc[0][2 * jj + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jj].y, acc[0][2 * jj + 1], 0, 0, 0);
-                acc[1][2 * jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jj].x, acc[1][2 * jj], 0, 0, 0);
-                acc[1][2 * jj + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jj].y, acc[1][2 * jj + 1], 0, 0, 0);
-            }
+            const float2 bv = *reinterpret_cast<const float2*>(B + (2 * s + hi) * KW);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
             if (do_bias && ((m + 2 * s + hi) % P.bias_stride) == 0) { bs0 += av.x; bs1 += av.y; }
         }
     };
@@ -108,7 +92,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     // software pipeline: stage st computes from LDS[st&1] while the loads of stages st+1 (landing) and st+2 (just issued)
     // are in flight; one barrier per stage.  nst is even (chunks are multiples of 64 rows).
     const int nst = (m1 - m0) / WG_R;
-    v4f p0a0, p0a1, p0a2, p0a3, p0b0, p0b1, p1a0, p1a1, p1a2, p1a3, p1b0, p1b1;
+    v4f p0a0, p0a1, p0b0, p1a0, p1a1, p1b0;
     WG_GLOAD(p0, m0);
     WG_GLOAD(p1, m0 + WG_R);
     WG_SSTORE(p0, 0);
@@ -126,16 +110,16 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     }
 #undef WG_GLOAD
 #undef WG_SSTORE
-    // acc[t][2jj+tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*128 + jj*64 + 2*lo + tp
+    // acc[t][tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*128 + kh*64 + 2*lo + tp
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int k = kcol0 + (jt >> 1) * 64 + 2 * lo + (jt & 1);
+        for (int tp = 0; tp < 2; ++tp) {
+            const int k = kcol0 + kh * 64 + 2 * lo + tp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + t;
-                if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][jt][r]);
+                if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
     if (do_bias) {
@@ -149,7 +133,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int task = blockIdx.x;
     int pi = 0;

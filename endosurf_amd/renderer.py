@@ -343,6 +343,8 @@ class EndoSurfRenderer(nn.Module):
         c = m._pack_cache
         if c is not None and c[0] == key:
             return c[1], c[2]
+        if c is not None and not want_grad and c[0] == (key[0], True):
+            return c[1].detach(), c[2]          # same weights already packed by a grad-enabled call: no need to repack
         if want_grad:
             weff, packed = _PackFn.apply(weakref.ref(m), self.engine, *plist)
         else:

@@ -38,6 +38,7 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     rays = renderer._rays32(batch["rays"])
     color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
     N = rays.shape[0]
+    renderer._weights()          # weight-norm + packing once per step, with the autograd node (ray marching below is no_grad)
     eod_pts, time = renderer._eod_points(rays, depth_gt)
     sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh)
     aux_x = torch.cat([eod_pts, sn_pts], 0)
