@@ -196,13 +196,15 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
     }
     if (nprob == 0) return ST_OK;
     ES_REQUIRE(nprob <= WG_MAX_PROBS, "too many weight-gradient problems in one group");
-    // rows per task: aim at ~2 tasks per CU per launch (each task owns a CU: 8 waves, 64 KB LDS)
-    double work = 0;
-    for (int i = 0; i < nprob; ++i) work += (double)probs[i].M * wg_kblk(probs[i]);
-    int MC = (int)(work / 1536.0);       // ~3 tasks per workgroup slot (2 slots per CU)
-    MC = (MC + 63) / 64 * 64;
-    if (MC < 128) MC = 128;
-    if (MC > 8192) MC = 8192;
+    // rows per task: the smallest chunk (multiple of 64 rows) for which the whole group fits in 3 full rounds of the
+    // 512 workgroup slots (2 per CU x 256 CUs) -- a 4th, nearly empty round would cost a quarter of the launch
+    auto count = [&](int mc) {
+        long long t = 0;
+        for (int i = 0; i < nprob; ++i) t += (long long)wg_kblk(probs[i]) * ((probs[i].M + mc - 1) / mc);
+        return t;
+    };
+    int MC = 128;
+    while (MC < 16384 && count(MC) > 3 * 512) MC += 64;
     WgArgs a;
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
