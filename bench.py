@@ -85,6 +85,21 @@ KERNEL_MACS = {"k_query_sdf": MAC_D + MAC_S, "k_deform_fwd": 4 * MAC_D, "k_sdf_f
                "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}
 
 
+def pmc_traffic(kernel_desc):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/pmc_summary.py); None if no profile matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    kname = kernel_desc.split(" ")[0].split("[")[0]
+    rows = [r for r in json.load(open(files[-1])) if r["kernel"].split("<")[0] == kname]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r: r["cycles"] * r["launches"])
+    return dict(hbm_bytes_per_launch=r["hbm_bytes"], source=os.path.basename(files[-1]), note="largest-grid launch group of this kernel")
+
+
 def kernel_timing(eng, step, first_step, n_steps):
     """A few extra steps of the SAME workload with the library's HIP-event timers on (events recorded on the launch stream
     around every chain / weight-gradient kernel).  Kept out of the headline region so the events do not perturb ``value``."""
@@ -175,7 +190,7 @@ def main():
             name, avg_ms, count = timing["dominant"]
             flops = timing["dominant_flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=None, kernel=name,
+            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=pmc_traffic(name), kernel=name,
                         avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
         out = dict(metric="training rays/sec (1024 rays x 64 samples)" if args.mode == "train" else "forward rays/sec (1024 rays x 64 samples)",
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,

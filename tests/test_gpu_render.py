@@ -62,3 +62,60 @@ def test_aux_forward(name):
     assert np.array_equal(inside.cpu().numpy(), c["eod/inside"])
     assert np.array_equal(np.isinf(d_i.cpu().numpy()), np.isinf(c["march64/d_i"]))
     assert abs(float(sn) - float(c["sn64/value"])) < 3 * abs(float(c["sn/value"]) - float(c["sn64/value"])) + 5e-5
+
+
+def test_config3_128_samples_eikonal():
+    """BASELINE config 3 shape (64 coarse + 64 importance samples, 16 new samples per up-sampling step) vs the fp64 oracle."""
+    import weightgen
+    from gpu_util import renderer_for
+    from oracle import endosurf_oracle as O
+    cfg = dict(net_chunk=80000, anneal_end=50000, n_samples=64, n_importance=64, important_begin_iter=0, up_sample_steps=4, perturb=False)
+    seed, n = 404, 24
+    r = renderer_for(seed, "trained", True, render_cfg=cfg)
+    assert r.n_samples + r.n_importance == 128
+    rays = weightgen.make_rays(seed + 1, n)
+    state = weightgen.make_state(seed, "trained", True)
+    R = O.OracleRenderer(O.OracleNet({k: torch.tensor(v, dtype=torch.float64) for k, v in state.items()}, True), cfg)
+    with torch.no_grad():
+        ret = r(torch.from_numpy(rays).cuda(), iter_step=20000)
+        ref = R.render_rays(torch.from_numpy(rays).double(), 20000, None)
+    assert tuple(ret["weights"].shape) == (n, 128) and tuple(ret["gradients_o"].shape) == (n, 128, 3)
+    assert err(ret["color_map"], ref["color_map"].numpy()) < 2e-4
+    assert err(ret["depth_map"], ref["depth_map"].numpy()) < 3e-4
+    assert abs(float(ret["gradient_o_error"]) - float(ref["gradient_o_error"])) < 2e-4 * max(1.0, float(ref["gradient_o_error"]))
+    assert err(ret["weights"], ref["weights"].numpy(), 0.995) < 1e-3
+
+
+def test_no_upsampling_before_important_begin_iter():
+    """iter_step < important_begin_iter: 32 coarse samples only (endosurf.py:85), tile-unaligned sample counts included."""
+    import weightgen
+    from gpu_util import renderer_for
+    from oracle import endosurf_oracle as O
+    cfg = dict(net_chunk=80000, anneal_end=0.0, n_samples=32, n_importance=32, important_begin_iter=1000, up_sample_steps=4, perturb=False)
+    seed, n = 505, 7          # 7 * 32 = 224 points: not a multiple of the 64-point tile
+    r = renderer_for(seed, "trained", False, render_cfg=cfg)
+    rays = weightgen.make_rays(seed + 1, n)
+    state = weightgen.make_state(seed, "trained", False)
+    R = O.OracleRenderer(O.OracleNet({k: torch.tensor(v, dtype=torch.float64) for k, v in state.items()}, False), cfg)
+    with torch.no_grad():
+        ret = r(torch.from_numpy(rays).cuda(), iter_step=5)
+        ref = R.render_rays(torch.from_numpy(rays).double(), 5, None)
+    assert tuple(ret["weights"].shape) == (n, 32)
+    assert err(ret["color_map"], ref["color_map"].numpy()) < 1e-4
+    assert err(ret["depth_map"], ref["depth_map"].numpy()) < 2e-4
+    assert err(ret["weights"], ref["weights"].numpy()) < 5e-4
+
+
+def test_empty_and_single_ray_batches():
+    from gpu_util import renderer_for
+    import weightgen
+    r = renderer_for(606, "init", True)
+    with torch.no_grad():
+        one = r(torch.from_numpy(weightgen.make_rays(1, 1)).cuda(), iter_step=1, perturb_overwrite=False)
+    assert tuple(one["color_map"].shape) == (1, 3) and torch.isfinite(one["color_map"]).all()
+    # a ray that misses the unit sphere: near == far, all samples coincide (utils.py:201-205) -> finite outputs
+    miss = torch.tensor([[0.0, 3.0, -1.5, 0.0, 0.0, 1.0, 0.0, 0.0, 0.3]]).cuda()
+    with torch.no_grad():
+        out = r(miss, iter_step=1, perturb_overwrite=False)
+    for k in ("color_map", "depth_map", "weights", "cdf"):
+        assert torch.isfinite(out[k]).all(), k

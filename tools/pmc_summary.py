@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (one directory per pass, csv output) into profiles/<tag>_pmc_summary.json.
+
+    python tools/pmc_summary.py <tag> <dir with SQ counters> <dir with FETCH_SIZE> <dir with WRITE_SIZE>
+
+Per (kernel, grid size): launches, mean cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs -> /8), MFMA utilisation =
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles), wait fractions, and HBM bytes per launch: FETCH_SIZE (KB) x 2 (gfx950
+counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB)."""
+import collections
+import csv
+import json
+import os
+import statistics as st
+import sys
+
+tag, d_sq, d_f, d_w = sys.argv[1:5]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def agg(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    f = [x for x in os.listdir(d) if x.endswith("counter_collection.csv")][0]
+    for x in csv.DictReader(open(os.path.join(d, f))):
+        k = x["Kernel_Name"].split("(")[0].replace("void ", "").replace("es::", "")
+        acc[(k, int(x["Grid_Size"]))][x["Counter_Name"]].append(float(x["Counter_Value"]))
+    return acc
+
+
+a, f, w = agg(d_sq), agg(d_f), agg(d_w)
+out = []
+for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
+    c = a[key]
+    if not key[0].startswith("k_") or "GRBM_GUI_ACTIVE" not in c:
+        continue
+    m = lambda n: st.mean(c[n]) if n in c else float("nan")
+    cyc = m("GRBM_GUI_ACTIVE") / 8
+    fetch = st.mean(f.get(key, {}).get("FETCH_SIZE", [float("nan")])) * 1024 * 2
+    write = st.mean(w.get(key, {}).get("WRITE_SIZE", [float("nan")])) * 1024
+    out.append(dict(kernel=key[0], grid_threads=key[1], launches=len(c["GRBM_GUI_ACTIVE"]), cycles=round(cyc),
+                    mfma_util=round(m("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * cyc), 4),
+                    wait_any=round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 4), wait_inst_any=round(m("SQ_WAIT_INST_ANY") / m("SQ_WAVE_CYCLES"), 4),
+                    hbm_fetch_bytes=round(fetch), hbm_write_bytes=round(write), hbm_bytes=round(fetch + write)))
+path = os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
+for o in out[:12]:
+    print(o)

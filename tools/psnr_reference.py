@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Train the REFERENCE renderer (CPU, build container only) on the synthetic scene and record the PSNR curve.
+
+    python tools/psnr_reference.py [n_iter] [n_rays]     -> tests/golden/psnr_reference.npz
+
+The loss arithmetic / Adam / LR schedule of trainer_endosurf.py:94-203 are restated here (the reference trainer cannot be
+imported offline: wandb/cv2/open3d/... are missing); the renderer itself is the reference's, unmodified."""
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import numpy as np
+import torch
+
+import make_golden as MG
+import synth_scene
+import weightgen
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+E = MG.import_reference()
+torch.set_num_threads(8)
+cfg = MG.load_cfg(True)
+state = weightgen.make_state(7, "init", True)
+r = MG.build_ref(E, cfg, state)
+opt = torch.optim.Adam([p for p in r.parameters()], lr=5e-4)
+sched = synth_scene.schedule(11, n_iter, n_rays)
+ev = {k: torch.from_numpy(v) for k, v in synth_scene.eval_batch().items()}
+
+
+def lr_factor(it, n_total=n_iter, warm=max(n_iter // 10, 1), alpha=0.05):
+    if it < warm:
+        return it / warm
+    prog = (it - warm) / (n_total - warm)
+    return (np.cos(np.pi * prog) + 1.0) * 0.5 * (1 - alpha) + alpha
+
+
+def psnr(a, b, m):
+    return float(20.0 * np.log10(1.0 / (((a - b) ** 2 * m).sum() / (m.sum() * 3.0 + 1e-10)) ** 0.5))
+
+
+curve, losses = [], []
+t0 = time.time()
+for it in range(1, n_iter + 1):
+    b = {k: torch.from_numpy(v) for k, v in sched[it - 1].items()}
+    for g in opt.param_groups:
+        g["lr"] = 5e-4 * lr_factor(it)
+    opt.zero_grad()
+    with torch.no_grad():
+        d_i = r.ray_marching(b["rays"], max_points=r.net_chunk)
+    valid = ((d_i.abs() != np.inf) & (d_i != 0) & (b["mask"] == 1))[:, 0]
+    with MG.patched_rng(b["u_perturb"], b["u_neigh"][valid]):
+        ret = r(b["rays"], iter_step=it)
+        color_loss = ((ret["color_map"] - b["color"]) * b["color_mask"]).abs().sum() / (b["color_mask"].sum() + 1e-10)
+        sdf_loss, angle_loss, vd = r.errorondepth(b["rays"], d_gt=b["depth"], mask=b["mask"], iter_step=it)
+        depth_loss = ((ret["depth_map"] - b["depth"]) * vd * b["mask"]).abs().sum() / ((vd * b["mask"]).sum() + 1e-10)
+        sn = r.surface_neighbour_error(rays=b["rays"], mask=b["mask"], iter_step=it, neighbour_rad=0.1)
+    loss = color_loss + depth_loss + sdf_loss + 0.1 * angle_loss + 0.1 * ret["gradient_o_error"] + 0.1 * sn
+    loss.backward()
+    opt.step()
+    losses.append(float(loss))
+    if it % 10 == 0 or it == 1:
+        with torch.no_grad():
+            e = r(ev["rays"], iter_step=it, perturb_overwrite=False)
+        curve.append((it, psnr(e["color_map"].numpy(), ev["color"].numpy(), ev["mask"].numpy()),
+                      float(((e["depth_map"] - ev["depth"]).abs() * ev["mask"]).sum() / ev["mask"].sum())))
+        print(f"it {it:4d} loss {float(loss):.4f} psnr {curve[-1][1]:.3f} depth_l1 {curve[-1][2]:.4f} ({time.time() - t0:.0f}s)", flush=True)
+np.savez(os.path.join(REPO, "tests", "golden", "psnr_reference.npz"), curve=np.array(curve, np.float64), loss=np.array(losses, np.float64),
+         n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11)
+print("saved")
