@@ -76,14 +76,18 @@ def test_config3_128_samples_eikonal():
     rays = weightgen.make_rays(seed + 1, n)
     state = weightgen.make_state(seed, "trained", True)
     R = O.OracleRenderer(O.OracleNet({k: torch.tensor(v, dtype=torch.float64) for k, v in state.items()}, True), cfg)
+    R32 = O.OracleRenderer(O.OracleNet({k: torch.tensor(v, dtype=torch.float32) for k, v in state.items()}, True), cfg)
     with torch.no_grad():
         ret = r(torch.from_numpy(rays).cuda(), iter_step=20000)
         ref = R.render_rays(torch.from_numpy(rays).double(), 20000, None)
+        r32 = R32.render_rays(torch.from_numpy(rays), 20000, None)
     assert tuple(ret["weights"].shape) == (n, 128) and tuple(ret["gradients_o"].shape) == (n, 128, 3)
-    assert err(ret["color_map"], ref["color_map"].numpy()) < 2e-4
-    assert err(ret["depth_map"], ref["depth_map"].numpy()) < 3e-4
+    # budget: 3x the fp32-vs-fp64 error of the oracle itself at this configuration (same rule as the golden cases)
+    bud = lambda k, floor, q=1.0: 3 * err(r32[k], ref[k].numpy(), q) + floor
+    assert err(ret["color_map"], ref["color_map"].numpy()) < bud("color_map", 2e-5)
+    assert err(ret["depth_map"], ref["depth_map"].numpy()) < bud("depth_map", 5e-5)
     assert abs(float(ret["gradient_o_error"]) - float(ref["gradient_o_error"])) < 2e-4 * max(1.0, float(ref["gradient_o_error"]))
-    assert err(ret["weights"], ref["weights"].numpy(), 0.995) < 1e-3
+    assert err(ret["weights"], ref["weights"].numpy(), 0.995) < bud("weights", 1e-4, 0.995)
 
 
 def test_no_upsampling_before_important_begin_iter():
