@@ -97,7 +97,7 @@ def pmc_traffic(kernel_desc):
     if not rows:
         return None
     r = max(rows, key=lambda r: r["cycles"] * r["launches"])
-    return dict(hbm_bytes_per_launch=r["hbm_bytes"], source=os.path.basename(files[-1]), note="largest-grid launch group of this kernel")
+    return r["hbm_bytes"], os.path.basename(files[-1])
 
 
 def kernel_timing(eng, step, first_step, n_steps):
@@ -190,7 +190,9 @@ def main():
             name, avg_ms, count = timing["dominant"]
             flops = timing["dominant_flops_per_launch"]
             ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=pmc_traffic(name), kernel=name,
+            tr = pmc_traffic(name)
+            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=tr[0] if tr else None,
+                        traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=tr[1] if tr else None, kernel=name,
                         avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
         out = dict(metric="training rays/sec (1024 rays x 64 samples)" if args.mode == "train" else "forward rays/sec (1024 rays x 64 samples)",
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,

@@ -105,7 +105,12 @@ class Trainer:
         self.renderer = renderer
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
-        self.optimizer = torch.optim.Adam(params=self.params, lr=lr)     # defaults like the reference (trainer_endosurf.py:70)
+        # Adam with the reference's defaults (trainer_endosurf.py:70); on the GPU the single-kernel "fused" implementation
+        # of the same update is used (81 parameter tensors -> one launch)
+        try:
+            self.optimizer = torch.optim.Adam(params=self.params, lr=lr, fused=self.params[0].is_cuda)
+        except (TypeError, RuntimeError):
+            self.optimizer = torch.optim.Adam(params=self.params, lr=lr)
         self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
         self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
         self.data_parallel = data_parallel
