@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--rays", type=int, default=N_RAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--schedule", default="fused", choices=["overlap", "fused", "plain"])
     args = ap.parse_args()
 
     from endosurf_amd import EndoSurfRenderer, parallel
@@ -147,7 +148,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
     renderer = EndoSurfRenderer(dict(RENDER_CFG), NET_CFG, device=dev)
-    trainer = Trainer(renderer, data_parallel=world > 1)
+    trainer = Trainer(renderer, data_parallel=world > 1, schedule=args.schedule)
     parallel.broadcast_parameters(trainer.params)
     scene = SyntheticScene(dev, seed=1234 + rank)
     batches = [scene.batch(args.rays) for _ in range(4)]      # resident in HBM before the timed region

@@ -175,8 +175,9 @@ class Engine:
         return out
 
     # ---- ray marching ------------------------------------------------------------------------------
-    def ray_marching(self, rays, weff, packed, use_deform, n_steps=128, n_secant_steps=8, tau=0.0):
-        """ray_marching + secant (reference endosurf.py:344-449), fixed shape. Returns d_pred [N,1]."""
+    def march_begin(self, rays, weff, packed, use_deform, n_steps=128, tau=0.0):
+        """First half of ray_marching (reference endosurf.py:352-406): SDF at n_steps proposals per ray (one big launch) and the
+        first sign change -> secant bracket. Returns the state consumed by march_refine."""
         N = rays.shape[0]
         dprop = self.empty(N, n_steps)
         self.ray_setup(rays, None, n_steps, 0.0, 1, dprop)
@@ -184,17 +185,28 @@ class Engine:
         state = self.empty(N, 4)
         flags = self.empty(N, dtype=torch.int32)
         d_pred = self.empty(N)
+        check(self.lib.es_march_find(ptr(sdf), ptr(dprop), N, n_steps, float(tau), ptr(state), ptr(flags), ptr(d_pred), stream_ptr()),
+              "es_march_find")
+        return dict(rays=rays, weff=weff, packed=packed, use_deform=use_deform, tau=float(tau), state=state, flags=flags, d_pred=d_pred,
+                    keep=(dprop, sdf))
+
+    def march_refine(self, ms, n_secant_steps=8):
+        """Second half (endosurf.py:410-449): n_secant_steps dependent secant iterations (latency-bound small launches)."""
+        rays, N = ms["rays"], ms["rays"].shape[0]
         st = stream_ptr()
-        check(self.lib.es_march_find(ptr(sdf), ptr(dprop), N, n_steps, float(tau), ptr(state), ptr(flags), ptr(d_pred), st), "es_march_find")
         x = self.empty(N, 3)
         t = self.empty(N)
         for _ in range(n_secant_steps):
-            check(self.lib.es_secant_points(ptr(rays), ptr(d_pred), N, ptr(x), ptr(t), st), "es_secant_points")
-            f_mid = self.query_sdf(self.points(x=x, t=t), weff, packed, use_deform)
-            check(self.lib.es_secant_update(ptr(f_mid), N, float(tau), ptr(state), ptr(d_pred), st), "es_secant_update")
+            check(self.lib.es_secant_points(ptr(rays), ptr(ms["d_pred"]), N, ptr(x), ptr(t), st), "es_secant_points")
+            f_mid = self.query_sdf(self.points(x=x, t=t), ms["weff"], ms["packed"], ms["use_deform"])
+            check(self.lib.es_secant_update(ptr(f_mid), N, ms["tau"], ptr(ms["state"]), ptr(ms["d_pred"]), st), "es_secant_update")
         d_out = self.empty(N, 1)
-        check(self.lib.es_march_finish(ptr(d_pred), ptr(flags), N, ptr(d_out), st), "es_march_finish")
+        check(self.lib.es_march_finish(ptr(ms["d_pred"]), ptr(ms["flags"]), N, ptr(d_out), st), "es_march_finish")
         return d_out
+
+    def ray_marching(self, rays, weff, packed, use_deform, n_steps=128, n_secant_steps=8, tau=0.0):
+        """ray_marching + secant (reference endosurf.py:344-449), fixed shape. Returns d_pred [N,1]."""
+        return self.march_refine(self.march_begin(rays, weff, packed, use_deform, n_steps, tau), n_secant_steps)
 
 
 class PointCtx:

@@ -367,7 +367,21 @@ class EndoSurfRenderer(nn.Module):
     def forward(self, rays, **kwargs):
         return self.render_rays(rays, **kwargs)
 
-    def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, aux_points=None, **kwargs):
+    def sample_z(self, rays, iter_step=0, perturb_overwrite=None, u_perturb=None):
+        """Sampling stage of render_rays (endosurf.py:63-110): coarse samples + SDF-guided up-sampling, no grad. -> z_vals [N, S]"""
+        rays = self._rays32(rays)
+        weff, packed = self._weights()
+        perturb = self.perturb if perturb_overwrite is None else perturb_overwrite
+        u = None
+        if perturb:
+            u = u_perturb if u_perturb is not None else torch.rand([rays.shape[0], 1], device=self.device)
+            u = u.detach().to(torch.float32).reshape(-1).contiguous()
+        upsample = iter_step >= self.important_begin_iter and self.n_importance > 0
+        with torch.no_grad():
+            return self.engine.sample_z(rays, u, weff.detach(), packed, self.use_deform, self.n_samples, self.n_importance,
+                                        self.up_sample_steps, upsample)
+
+    def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, aux_points=None, z_vals=None, **kwargs):
         """reference render_rays (endosurf.py:60-132).  ``u_perturb`` ([N] or [N,1] uniform draws) may be supplied to
         make the stratified jitter reproducible; otherwise it is drawn with torch.rand on the device like the reference.
         ``aux_points=(x [Ma,3], t [Ma])``: extra colour-less points evaluated in the same launches; their network outputs
@@ -375,15 +389,7 @@ class EndoSurfRenderer(nn.Module):
         rays = self._rays32(rays)
         n_rays = rays.shape[0]
         weff, packed = self._weights()
-        perturb = self.perturb if perturb_overwrite is None else perturb_overwrite
-        u = None
-        if perturb:
-            u = u_perturb if u_perturb is not None else torch.rand([n_rays, 1], device=self.device)
-            u = u.detach().to(torch.float32).reshape(-1).contiguous()
-        upsample = iter_step >= self.important_begin_iter and self.n_importance > 0
-        with torch.no_grad():
-            z = self.engine.sample_z(rays, u, weff.detach(), packed, self.use_deform, self.n_samples, self.n_importance,
-                                     self.up_sample_steps, upsample)
+        z = z_vals if z_vals is not None else self.sample_z(rays, iter_step, perturb_overwrite, u_perturb)
         sample_dist = 2.0 / self.n_samples
         ret = self.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist,
                                cos_anneal_ratio=self.get_cos_anneal_ratio(iter_step), eval=eval, _rays=rays, _aux=aux_points)
@@ -468,12 +474,22 @@ class EndoSurfRenderer(nn.Module):
         _, g = self._point_eval(pp, tt)
         return self._sn_loss(g, valid)
 
-    def _sn_points(self, rays, mask, neighbour_rad, u_neigh=None):
+    def _march_begin(self, rays):
+        weff, packed = self._weights()
+        with torch.no_grad():
+            return self.engine.march_begin(self._rays32(rays), weff.detach(), packed, self.use_deform)
+
+    def _march_refine(self, ms):
+        with torch.no_grad():
+            return self.engine.march_refine(ms)
+
+    def _sn_points(self, rays, mask, neighbour_rad, u_neigh=None, d_i=None):
         N = rays.shape[0]
         rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
         rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
         with torch.no_grad():
-            d_i = self.ray_marching(rays)
+            if d_i is None:
+                d_i = self.ray_marching(rays)
             valid = (torch.isfinite(d_i) & (d_i != 0) & (mask == 1))[:, 0]
             d_safe = torch.where(valid[:, None], d_i, torch.zeros_like(d_i))
             p_surf = rays_o + d_safe * rays_d_z

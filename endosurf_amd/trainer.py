@@ -40,11 +40,60 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     N = rays.shape[0]
     renderer._weights()          # weight-norm + packing once per step, with the autograd node (ray marching below is no_grad)
     eod_pts, time = renderer._eod_points(rays, depth_gt)
-    sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh)
+    # The 128-proposal ray-marching query fills the GPU; the 8 secant iterations after it and the hierarchical sampling
+    # (coarse query + 3 dependent 8-sample queries) are independent chains of small, latency-bound launches: run the sampling
+    # on a side stream WHILE the main stream iterates the secant (two throughput-bound kernels would only slow each other)
+    main = torch.cuda.current_stream(rays.device)
+    side = getattr(renderer, "_side_stream", None)
+    if side is None:
+        side = renderer._side_stream = torch.cuda.Stream(device=rays.device)
+    ms = renderer._march_begin(rays)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
+    d_i = renderer._march_refine(ms)
+    sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh, d_i=d_i)
+    main.wait_stream(side)
+    z.record_stream(main)
     aux_x = torch.cat([eod_pts, sn_pts], 0)
     aux_t = torch.cat([time, sn_t], 0)
-    ret = renderer(rays, iter_step=iter_step, u_perturb=u_perturb, aux_points=(aux_x, aux_t))
+    ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
     a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
+    color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
+    sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
+    depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
+    eik = ret["gradient_o_error"]
+    sn = renderer._sn_loss(a_go[N:], valid_sn)
+    total = (color_loss * weights["color"] + depth_loss * weights["depth"] + sdf_loss * weights["sdf"]
+             + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
+    terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
+    return total, terms, ret
+
+
+def compute_loss_overlapped(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
+                            u_perturb=None, u_neigh=None):
+    """Same loss as compute_loss on two HIP streams: the main stream renders (sampling, fused point evaluation, compositing)
+    while a side stream runs the latency-bound chain ray marching -> 8 secant steps -> point evaluation of the 3N auxiliary
+    points (errorondepth + surface neighbours).  The small launches of either stream fill the tails of the other's large
+    ones, and autograd replays each branch's backward on the stream its forward ran on, so the backward overlaps too."""
+    rays = renderer._rays32(batch["rays"])
+    color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
+    N = rays.shape[0]
+    dev = rays.device
+    renderer._weights()          # weight-norm + packing once per step, with the autograd node, before the streams fork
+    main = torch.cuda.current_stream(dev)
+    side = getattr(renderer, "_side_stream", None)
+    if side is None:
+        side = renderer._side_stream = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        eod_pts, time = renderer._eod_points(rays, depth_gt)
+        sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh)
+        a_sdf, a_go = renderer._point_eval(torch.cat([eod_pts, sn_pts], 0), torch.cat([time, sn_t], 0))
+    ret = renderer(rays, iter_step=iter_step, u_perturb=u_perturb)
+    main.wait_stream(side)
+    for t in (eod_pts, valid_sn, a_sdf, a_go):
+        t.record_stream(main)
     color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
     sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
     depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
@@ -101,7 +150,8 @@ class Trainer:
     """zero_grad -> compute_loss -> backward -> (data-parallel gradient all-reduce) -> Adam  (train_step, trainer_endosurf.py:94-104)."""
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
-                 loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True):
+                 loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
+                 schedule: str = None):
         self.renderer = renderer
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
@@ -114,7 +164,9 @@ class Trainer:
         self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
         self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
         self.data_parallel = data_parallel
-        self.loss_fn = compute_loss_fused if fused else compute_loss
+        # "overlap": two-stream schedule; "fused": auxiliary points inside the render launches; "plain": reference call sequence
+        schedule = schedule or ("fused" if fused else "plain")
+        self.loss_fn = {"overlap": compute_loss_overlapped, "fused": compute_loss_fused, "plain": compute_loss}[schedule]
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)

@@ -157,7 +157,7 @@ def test_training_loss_param_grads(name):
 @pytest.mark.parametrize("name", ["trained_deform", "trained_nodeform"])
 def test_fused_training_loss_matches_unfused(name):
     """compute_loss_fused (aux points inside the render launches) == compute_loss (three separate evaluations)."""
-    from endosurf_amd.trainer import compute_loss, compute_loss_fused
+    from endosurf_amd.trainer import compute_loss, compute_loss_fused, compute_loss_overlapped
     c = load_case(name)
     dev = "cuda"
     batch = dict(rays=torch.from_numpy(c["rays"]).to(dev), color=torch.from_numpy(c["target/color"]).to(dev),
@@ -166,19 +166,20 @@ def test_fused_training_loss_matches_unfused(name):
     u = torch.from_numpy(c["u_perturb"]).to(dev) if "u_perturb" in c else None
     un = torch.from_numpy(c["u_neigh"]).to(dev)
     res = []
-    for fn in (compute_loss, compute_loss_fused):
+    for fn in (compute_loss, compute_loss_fused, compute_loss_overlapped):
         r = renderer_for_case(c)
         r.perturb = u is not None
         total, terms, _ = fn(r, batch, int(c["meta/iter_step"]), u_perturb=u, u_neigh=un)
         total.backward()
         torch.cuda.synchronize()
         res.append((float(total), {k: float(v) for k, v in terms.items()}, {k: p.grad.clone() for k, p in r.named_parameters()}))
-    (t0, terms0, g0), (t1, terms1, g1) = res
-    assert abs(t0 - t1) < 1e-5 * max(1.0, abs(t0)), (t0, t1)
-    for k in terms0:
-        assert abs(terms0[k] - terms1[k]) < 1e-5 * max(1.0, abs(terms0[k])), k
-    for k in g0:
-        n = float(g0[k].norm())
-        assert float((g0[k] - g1[k]).norm()) <= 2e-4 * n + 1e-7, (k, float((g0[k] - g1[k]).norm()), n)
+    (t0, terms0, g0), (t1, terms1, g1), (t2, terms2, g2) = res
+    for tb, termsb, gb in ((t1, terms1, g1), (t2, terms2, g2)):
+        assert abs(t0 - tb) < 1e-5 * max(1.0, abs(t0)), (t0, tb)
+        for k in terms0:
+            assert abs(terms0[k] - termsb[k]) < 1e-5 * max(1.0, abs(terms0[k])), k
+        for k in g0:
+            n = float(g0[k].norm())
+            assert float((g0[k] - gb[k]).norm()) <= 2e-4 * n + 1e-7, (k, float((g0[k] - gb[k]).norm()), n)
     t64 = float(c["loss64/total"])
     assert abs(t1 - t64) < 3 * abs(float(c["loss/total"]) - t64) + 5e-5 * max(1.0, abs(t64))
