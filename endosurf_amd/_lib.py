@@ -28,6 +28,13 @@ class es_composite_args(C.Structure):
                                              "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc")])
 
 
+class es_loss_args(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("color_map", "depth_map", "eik", "aux_sdf", "aux_go", "rays", "eod_pts", "color_gt", "depth_gt",
+                                            "mask", "cmask", "valid_sn")]
+                + [("N", C.c_int)] + [(n, C.c_float) for n in ("w_color", "w_depth", "w_sdf", "w_angle", "w_eik", "w_sn")]
+                + [(n, C.c_void_p) for n in ("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go")])
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -62,6 +69,7 @@ PROTOTYPES = {
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "es_train_loss": (_I, [C.POINTER(es_loss_args), _P]),
     "es_timing_enable": (_I, [_I]),
     "es_timing_drain": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "es_kernel_name": (C.c_char_p, [_I]),

@@ -4,6 +4,7 @@
 #include "arch.h"
 #include "chain_common.h"
 #include "launch.h"
+#include "loss_args.h"
 #include "ray_args.h"
 #include "workspace.h"
 
@@ -16,6 +17,8 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st);
+int train_loss(const LossArgs& a, hipStream_t st);
+static_assert(sizeof(es_loss_args) == sizeof(LossArgs), "es_loss_args must mirror es::LossArgs");
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
 int upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
@@ -189,6 +192,13 @@ int es_point_backward(const es_points* pts, const float* packed, const float* we
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
     return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, (hipStream_t)stream);
+}
+
+int es_train_loss(const es_loss_args* a, void* stream) {
+    ES_REQUIRE(a && a->color_map && a->depth_map && a->eik && a->aux_sdf && a->aux_go && a->rays && a->eod_pts && a->color_gt &&
+               a->depth_gt && a->mask && a->cmask && a->valid_sn, "es_train_loss inputs");
+    ES_REQUIRE(a->terms && a->g_color && a->g_depth && a->g_eik && a->g_aux_sdf && a->g_aux_go, "es_train_loss outputs");
+    return train_loss(*reinterpret_cast<const LossArgs*>(a), (hipStream_t)stream);
 }
 
 }  // extern "C"

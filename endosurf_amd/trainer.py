@@ -32,7 +32,7 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
 
 
 def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                       u_perturb=None, u_neigh=None):
+                       u_perturb=None, u_neigh=None, loss_kernel: bool = True):
     """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
     inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
     rays = renderer._rays32(batch["rays"])
@@ -59,6 +59,10 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     aux_t = torch.cat([time, sn_t], 0)
     ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
     a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
+    if loss_kernel:
+        total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], ret["gradient_o_error"], a_sdf, a_go, renderer.engine, rays, eod_pts,
+                                 color_gt, depth_gt, mask_gt, cmask, valid_sn, weights)
+        return total, dict(color=t[0], depth=t[1], sdf=t[2], angle=t[3], eikonal=t[4], surf_neig=t[5]), ret
     color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
     sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
     depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
@@ -103,6 +107,42 @@ def compute_loss_overlapped(renderer, batch: Dict[str, torch.Tensor], iter_step:
              + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
     terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
     return total, terms, ret
+
+
+class _LossFn(torch.autograd.Function):
+    """All six loss terms + total and their gradients in one HIP launch (es_train_loss)."""
+
+    @staticmethod
+    def forward(ctx, color_map, depth_map, eik, aux_sdf, aux_go, eng, rays, eod_pts, color_gt, depth_gt, mask, cmask, valid_sn, w):
+        import ctypes as C
+        from . import _lib
+        N = rays.shape[0]
+        if mask.numel() != N or cmask.numel() != N or valid_sn.numel() != N or aux_sdf.numel() != 3 * N:
+            raise ValueError("es_train_loss expects per-ray masks [N,1] and 3N auxiliary points")
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        ins = [f(color_map), f(depth_map), f(eik).reshape(1), f(aux_sdf), f(aux_go), f(rays), f(eod_pts), f(color_gt), f(depth_gt), f(mask),
+               f(cmask), valid_sn.to(torch.uint8).contiguous()]
+        terms = eng.empty(8)
+        grads = [eng.empty(N, 3), eng.empty(N, 1), eng.empty(1), eng.empty(3 * N, 1), eng.empty(3 * N, 3)]
+        a = _lib.es_loss_args()
+        for name, t in zip(("color_map", "depth_map", "eik", "aux_sdf", "aux_go", "rays", "eod_pts", "color_gt", "depth_gt", "mask", "cmask",
+                            "valid_sn"), ins):
+            setattr(a, name, _lib.ptr(t))
+        a.N = N
+        a.w_color, a.w_depth, a.w_sdf, a.w_angle, a.w_eik, a.w_sn = (float(w[k]) for k in ("color", "depth", "sdf", "angle", "eikonal", "surf_neig"))
+        for name, t in zip(("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go"), [terms] + grads):
+            setattr(a, name, _lib.ptr(t))
+        _lib.check(eng.lib.es_train_loss(C.byref(a), _lib.stream_ptr()), "es_train_loss")
+        ctx.grads = grads
+        ctx.eik_shape = eik.shape
+        ctx.mark_non_differentiable(terms)
+        return terms[6].clone(), terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        gc, gd, ge, gs, gg = ctx.grads
+        return (gc * g_total, gd * g_total, (ge * g_total).reshape(ctx.eik_shape), gs * g_total, gg * g_total,
+                None, None, None, None, None, None, None, None, None)
 
 
 def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
