@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--rays", type=int, default=N_RAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
-    ap.add_argument("--schedule", default="fused", choices=["overlap", "fused", "plain"])
+    ap.add_argument("--schedule", default="fused", choices=["overlap", "fused", "split", "plain"])
     args = ap.parse_args()
 
     from endosurf_amd import EndoSurfRenderer, parallel

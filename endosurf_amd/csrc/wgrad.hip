@@ -85,7 +85,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
-            if (do_bias && ((m + 2 * s + hi) % P.bias_stride) == 0) { bs0 += av.x; bs1 += av.y; }
+            if (do_bias && ((m + 2 * s + hi) & (P.bias_stride - 1)) == 0) { bs0 += av.x; bs1 += av.y; }
         }
     };
 
@@ -143,7 +143,16 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     const WgProb& P = a.p[pi];
     const int local = task - P.task_begin;
     const int kblk = (P.K + WG_KW - 1) / WG_KW;
-    const int kb = local % kblk, mc = local / kblk;
+    // the kblk tasks of one row chunk read the same dA rows: give them block ids 8 apart (same XCD under the round-robin
+    // block -> XCD dispatch, started back to back) so that the second reader hits that XCD's L2 instead of HBM
+    int kb, mc;
+    if (kblk == 2) {
+        const int nchunk = (P.M + a.MC - 1) / a.MC;
+        const int grp = local / 16, j = local % 16;
+        const int full = (nchunk / 8) * 8;                 // chunks covered by complete groups of 8
+        if (grp * 8 < full) { mc = grp * 8 + (j & 7); kb = j >> 3; }
+        else { const int rem = local - 2 * full; kb = rem & 1; mc = full + (rem >> 1); }
+    } else { kb = local % kblk; mc = local / kblk; }
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
     wgrad_task(P, kb, m0, m1, wlds);
 }
@@ -209,6 +218,7 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         ES_REQUIRE(probs[i].lda == 256 && probs[i].M % 64 == 0, "weight-gradient operands must be [64k][256] adjoints");
+        ES_REQUIRE((probs[i].bias_stride & (probs[i].bias_stride - 1)) == 0, "bias stride must be a power of two");
         probs[i].task_begin = total;
         total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
         a.p[i] = probs[i];

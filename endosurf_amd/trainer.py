@@ -32,7 +32,7 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
 
 
 def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                       u_perturb=None, u_neigh=None, loss_kernel: bool = True):
+                       u_perturb=None, u_neigh=None, loss_kernel: bool = True, split_aux: bool = False):
     """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
     inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
     rays = renderer._rays32(batch["rays"])
@@ -57,8 +57,19 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     z.record_stream(main)
     aux_x = torch.cat([eod_pts, sn_pts], 0)
     aux_t = torch.cat([time, sn_t], 0)
-    ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
-    a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
+    if split_aux:
+        # the 3N auxiliary points as their own (small) launches on the side stream, concurrent with the render's: they fill
+        # the slots the render's kernels free at the end of their last full round instead of adding a nearly empty round
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            a_sdf, a_go = renderer._point_eval(aux_x, aux_t)
+        ret = renderer(rays, iter_step=iter_step, z_vals=z)
+        main.wait_stream(side)
+        a_sdf.record_stream(main)
+        a_go.record_stream(main)
+    else:
+        ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
+        a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
     if loss_kernel:
         total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], ret["gradient_o_error"], a_sdf, a_go, renderer.engine, rays, eod_pts,
                                  color_gt, depth_gt, mask_gt, cmask, valid_sn, weights)
@@ -72,6 +83,10 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
              + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
     terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
     return total, terms, ret
+
+
+def compute_loss_split(renderer, batch, iter_step, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, u_perturb=None, u_neigh=None):
+    return compute_loss_fused(renderer, batch, iter_step, weights, surf_neig_rad, u_perturb, u_neigh, split_aux=True)
 
 
 def compute_loss_overlapped(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
@@ -206,7 +221,7 @@ class Trainer:
         self.data_parallel = data_parallel
         # "overlap": two-stream schedule; "fused": auxiliary points inside the render launches; "plain": reference call sequence
         schedule = schedule or ("fused" if fused else "plain")
-        self.loss_fn = {"overlap": compute_loss_overlapped, "fused": compute_loss_fused, "plain": compute_loss}[schedule]
+        self.loss_fn = {"overlap": compute_loss_overlapped, "fused": compute_loss_fused, "split": compute_loss_split, "plain": compute_loss}[schedule]
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)

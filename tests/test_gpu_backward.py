@@ -157,7 +157,7 @@ def test_training_loss_param_grads(name):
 @pytest.mark.parametrize("name", ["trained_deform", "trained_nodeform"])
 def test_fused_training_loss_matches_unfused(name):
     """compute_loss_fused (aux points inside the render launches) == compute_loss (three separate evaluations)."""
-    from endosurf_amd.trainer import compute_loss, compute_loss_fused, compute_loss_overlapped
+    from endosurf_amd.trainer import compute_loss, compute_loss_fused, compute_loss_overlapped, compute_loss_split
     c = load_case(name)
     dev = "cuda"
     batch = dict(rays=torch.from_numpy(c["rays"]).to(dev), color=torch.from_numpy(c["target/color"]).to(dev),
@@ -166,15 +166,15 @@ def test_fused_training_loss_matches_unfused(name):
     u = torch.from_numpy(c["u_perturb"]).to(dev) if "u_perturb" in c else None
     un = torch.from_numpy(c["u_neigh"]).to(dev)
     res = []
-    for fn in (compute_loss, compute_loss_fused, compute_loss_overlapped):
+    for fn in (compute_loss, compute_loss_fused, compute_loss_overlapped, compute_loss_split):
         r = renderer_for_case(c)
         r.perturb = u is not None
         total, terms, _ = fn(r, batch, int(c["meta/iter_step"]), u_perturb=u, u_neigh=un)
         total.backward()
         torch.cuda.synchronize()
         res.append((float(total), {k: float(v) for k, v in terms.items()}, {k: p.grad.clone() for k, p in r.named_parameters()}))
-    (t0, terms0, g0), (t1, terms1, g1), (t2, terms2, g2) = res
-    for tb, termsb, gb in ((t1, terms1, g1), (t2, terms2, g2)):
+    (t0, terms0, g0), (t1, terms1, g1) = res[:2]
+    for tb, termsb, gb in res[1:]:
         assert abs(t0 - tb) < 1e-5 * max(1.0, abs(t0)), (t0, tb)
         for k in terms0:
             assert abs(terms0[k] - termsb[k]) < 1e-5 * max(1.0, abs(terms0[k])), k
