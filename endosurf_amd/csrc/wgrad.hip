@@ -47,10 +47,15 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     auto Bpan = [&](int buf) { return lds + 2 * WG_R * 256 + buf * (WG_R * KW); };
     const int kcol0 = kb * KW;
 
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
     f32x16 acc[2][2];
     acc_zero(acc);
-    float bs0 = 0.f, bs1 = 0.f;
-    const bool do_bias = P.bias_out != nullptr && kb == 0 && kh == 0;
+    // bias gradient = column sums of dA over the rows r with r % bias_stride == 0 (strides 1 or 4; stages start at multiples
+    // of 16): taken from the staging registers on their way to LDS (thread tid holds columns 4*(tid&63).. of rows tid>>6 and
+    // 8 + (tid>>6) of every stage), so the MFMA loop stays one branch-free basic block per stage
+    const bool do_bias = P.bias_out != nullptr && kb == 0;
+    const float bmask = (do_bias && ((tid >> 6) & (P.bias_stride - 1)) == 0) ? 1.f : 0.f;
+    v4f_t bsum = {0.f, 0.f, 0.f, 0.f};
 
     // global -> register loads of one 16-row stage (two stages in flight: sets 0/1), register -> LDS stores.
     // Plain ext-vector locals (not HIP float4 structs) so that they stay in VGPRs.
@@ -73,8 +78,9 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
         *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                         \
         *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = S##a1;                                         \
         *reinterpret_cast<v4f*>(Bpan(buf) + 4 * tid) = S##b0;                                         \
+        bsum += bmask * (S##a0 + S##a1);                                                              \
     }
-    auto compute = [&](int buf, int m) {
+    auto compute = [&](int buf) {
         const float* A = Apan(buf) + nb * 64 + 2 * lo;
         const float* B = Bpan(buf) + kh * 64 + 2 * lo;
 #pragma unroll
@@ -85,7 +91,6 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
-            if (do_bias && ((m + 2 * s + hi) & (P.bias_stride - 1)) == 0) { bs0 += av.x; bs1 += av.y; }
         }
     };
 
@@ -100,11 +105,11 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
 #pragma unroll 1
     for (int st = 0; st < nst; st += 2) {
         if (st + 2 < nst) WG_GLOAD(p0, m0 + WG_R * (st + 2));
-        compute(0, m0 + WG_R * st);
+        compute(0);
         WG_SSTORE(p1, 1);                                // stage st+1 (loaded one iteration ago)
         __syncthreads();
         if (st + 3 < nst) WG_GLOAD(p1, m0 + WG_R * (st + 3));
-        compute(1, m0 + WG_R * (st + 1));
+        compute(1);
         if (st + 2 < nst) WG_SSTORE(p0, 0);              // stage st+2
         __syncthreads();
     }
@@ -122,13 +127,15 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
                 if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
-    if (do_bias) {
-        bs0 += __shfl_xor(bs0, 32, 64);
-        bs1 += __shfl_xor(bs1, 32, 64);
-        if (hi == 0) {
-            const int n = nb * 64 + 2 * lo;
-            if (n < P.N) atomicAdd(P.bias_out + n, bs0);
-            if (n + 1 < P.N) atomicAdd(P.bias_out + n + 1, bs1);
+    if (do_bias) {      // workgroup-uniform: reduce the 8 row-waves' partial column sums through LDS (all stages consumed)
+        __syncthreads();
+        *reinterpret_cast<v4f*>(lds + 4 * tid) = bsum;
+        __syncthreads();
+        if (tid < 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += lds[r * 256 + tid];
+            if (tid < P.N) atomicAdd(P.bias_out + tid, s);
         }
     }
 }
