@@ -503,7 +503,85 @@ class EndoSurfRenderer(nn.Module):
         diff = (normal[:N] - normal[N:]).abs() * valid[:, None].to(self.dtype)
         return diff.sum() / torch.clamp(valid.sum() * 3, min=1).to(self.dtype)
 
-    # ---- offline helpers (reference endosurf.py:490-521) -----------------------------------------------------------------
+    # ---- offline helpers (reference endosurf.py:450-521) -----------------------------------------------------------------
+    def _points_color(self, x, t, dirs):
+        """(rgb [M,3], g_o [M,3]) at explicit points, no grad: one deform/SDF/colour chain launch (EndoSurfNet.forward
+        endosurf.py:660-689 + get_sdf_grad_from_observed_space :581-601 in the same pass)."""
+        weff, packed = self._weights()
+        f = lambda a, w: a.detach().to(device=self.device, dtype=torch.float32).reshape(-1, w).contiguous()
+        x, dirs = f(x, 3), f(dirs, 3)
+        t = f(t, 1).reshape(-1)
+        assert t.numel() in (1, x.shape[0]), "ts must hold one time per point or a single shared time"
+        with torch.no_grad():
+            pts = self.engine.points(x=x, t=t, dirs=dirs)
+            pctx = self.engine.point_forward(pts, weff.detach(), packed, (_lib.PF_DEFORM if self.use_deform else 0) | _lib.PF_COLOR)
+            return pctx.view("rgb").clone(), pctx.view("go").clone()
+
+    def renderonpts(self, pts, dirs, ts, net_chunk=80000, cpu=True):
+        """Surface rendering at given points (reference endosurf.py:502-521): colour (torch, on device) and unit normal
+        (numpy if ``cpu`` else torch), shaped like ``pts``.  ``ts``: [M,1] or the shared-time form [1].  ``net_chunk`` bounds
+        the points per launch like the reference's run_fn_split."""
+        sh = list(pts.shape[:-1])
+        x, d = pts.reshape(-1, 3), dirs.reshape(-1, 3)
+        ts = torch.as_tensor(ts, device=self.device)
+        colors, normals = [], []
+        for i in range(0, max(x.shape[0], 1), int(net_chunk)):
+            tt = ts if ts.numel() == 1 else ts.reshape(-1)[i:i + net_chunk]
+            rgb, g = self._points_color(x[i:i + net_chunk], tt, d[i:i + net_chunk])
+            colors.append(rgb)
+            normals.append(g / (torch.linalg.norm(g, ord=2, dim=-1, keepdim=True) + 1e-10))
+        color = torch.cat(colors, 0).reshape(*sh, 3)
+        normal = torch.cat(normals, 0).reshape(*sh, 3)
+        return color, (normal.cpu().numpy() if cpu else normal)
+
+    def renderondepth(self, rays, depth):
+        """Surface rendering at a given depth per ray (reference endosurf.py:450-488): (colour [N,3], g_o [N,3], d_out [N,1]);
+        rays with depth <= 0 or +inf give zeros, +inf depths are replaced by the far sphere intersection in d_out.
+        Fixed shape on the device: every ray is evaluated (at depth 0 when invalid) and masked, no host round trip."""
+        rays = self._rays32(rays)
+        depth = depth.detach().to(device=self.device, dtype=torch.float32).reshape(-1, 1)
+        N = rays.shape[0]
+        with torch.no_grad():
+            _, far = self.engine.ray_setup(rays, None, 2, 1.0, 0, self.engine.empty(N, 2), want_bounds=True)
+            inf = depth == float("inf")
+            valid = (depth > 0) & ~inf
+            d_out = torch.where(inf, far.view(-1, 1), depth)
+            d_eval = torch.where(valid, depth, torch.zeros_like(depth))
+            rays_d = rays[:, 3:6]
+            pts = rays[:, :3] + rays_d / (rays_d[:, 2:] + 1e-6) * d_eval
+            rgb, g = self._points_color(pts, rays[:, 8], rays_d)
+            z = torch.zeros_like(rgb)
+            return torch.where(valid, rgb, z), torch.where(valid, g, z), d_out
+
+    def extract_fields(self, bound_min, bound_max, resolution, t, net_chunk=1 << 22):
+        """SDF on a resolution^3 linspace grid at time ``t`` (reference extract_fields, utils.py:139-157, with the query of
+        extract_observation_geometry): the grid coordinates are generated on the device, sampled by the fused query kernel in
+        launches of ``net_chunk`` points and returned with ONE device-to-host copy as numpy [R,R,R] (x-major like the reference)."""
+        R = int(resolution)
+        bmin = torch.as_tensor(bound_min, dtype=torch.float32).cpu()
+        bmax = torch.as_tensor(bound_max, dtype=torch.float32).cpu()
+        ax = [torch.linspace(float(bmin[i]), float(bmax[i]), R, device=self.device) for i in range(3)]
+        tt = torch.as_tensor(t, dtype=torch.float32, device=self.device).reshape(-1)[:1]
+        u = torch.empty(R * R * R, device=self.device)
+        per_x = max(1, int(net_chunk) // (R * R))
+        for i in range(0, R, per_x):
+            xx, yy, zz = torch.meshgrid(ax[0][i:i + per_x], ax[1], ax[2], indexing="ij")
+            pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+            u[i * R * R:(i + per_x) * R * R] = self.sdf_observed(pts, tt).reshape(-1)
+        return u.reshape(R, R, R).cpu().numpy()
+
+    def extract_observation_geometry(self, t, bound_min, bound_max, resolution, threshold=0.0, net_chunk=1 << 22, cpu=True):
+        """(vertices, triangles) of the observed-space surface at time t (reference endosurf.py:490-500 + extract_geometry,
+        utils.py:128-136).  Field sampling runs on the GPU; the iso-surface extractor is PyMCubes when installed (as in the
+        reference), otherwise endosurf_amd.meshing.marching_tetrahedra (different triangulation of the same level set)."""
+        from .meshing import iso_surface
+        u = self.extract_fields(bound_min, bound_max, resolution, t, net_chunk)
+        vertices, triangles = iso_surface(u, threshold)
+        b_max = torch.as_tensor(bound_max, dtype=torch.float32).cpu().numpy()
+        b_min = torch.as_tensor(bound_min, dtype=torch.float32).cpu().numpy()
+        vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
+        return vertices, triangles
+
     def sdf_observed(self, pts, t):
         """get_sdf_from_observed_space (endosurf.py:570-579) for [M,3] points and [M] / scalar time, no grad."""
         weff, packed = self._weights()

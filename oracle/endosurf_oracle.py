@@ -409,6 +409,43 @@ class OracleRenderer:
         angle_error = relu_cos.abs().sum() / denom
         return sdf_error, angle_error, inside
 
+    # -- offline helpers (surface rendering / meshing field), SURVEY 8f-3 ---------------------------------
+    def renderonpts(self, pts, dirs, ts):
+        """renderonpts (endosurf.py:502-521): colour and unit normal at given points; ``ts`` is [M,1] or the shared-time
+        form [1] (DeformNetwork.forward, endosurf.py:726-727)."""
+        sh = list(pts.shape[:-1])
+        x, d = pts.reshape(-1, 3), dirs.reshape(-1, 3)
+        t = ts[None, :].expand(x.shape[0], 1) if ts.dim() == 1 else ts.reshape(-1, 1)
+        pe = self.net.point_eval(x, d, t, with_color=True)
+        normal = pe["g_o"] / (pe["g_o"].norm(dim=-1, keepdim=True) + 1e-10)
+        return pe["rgb"].reshape(*sh, 3), normal.reshape(*sh, 3)
+
+    def renderondepth(self, rays, depth):
+        """renderondepth (endosurf.py:450-488): colour / g_o at o + d_z*depth for rays with 0 < depth < inf, zeros elsewhere;
+        d_out = depth with +inf replaced by the far sphere intersection."""
+        o, d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+        _, far = sphere_intersection(o, d)
+        valid = (depth[:, 0] > 0) & (depth[:, 0] != float("inf"))
+        d_out = torch.where(depth == float("inf"), far, depth)
+        color = torch.zeros(rays.shape[0], 3, dtype=rays.dtype)
+        grad = torch.zeros(rays.shape[0], 3, dtype=rays.dtype)
+        if valid.any():
+            pts = o[valid] + d_over_z(d)[valid] * depth[valid]
+            pe = self.net.point_eval(pts, d[valid], time[valid][:, None], with_color=True)
+            color[valid] = pe["rgb"]
+            grad[valid] = pe["g_o"]
+        return color, grad, d_out
+
+    def extract_fields(self, bound_min, bound_max, resolution, t):
+        """extract_fields (utils.py:139-157) with the query of extract_observation_geometry (endosurf.py:490-500):
+        u[i,j,k] = sdf(x_i, y_j, z_k; t) on linspace grids (the reference's 128-blocking only bounds memory)."""
+        dt = bound_min.dtype
+        ax = [torch.linspace(float(bound_min[i]), float(bound_max[i]), resolution, dtype=dt) for i in range(3)]
+        xx, yy, zz = torch.meshgrid(*ax, indexing="ij")
+        pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+        tt = torch.as_tensor(t, dtype=dt).reshape(1, 1).expand(pts.shape[0], 1)
+        return self.net.sdf_observed(pts, tt).reshape(resolution, resolution, resolution)
+
     def ray_marching(self, rays, n_steps=128, n_secant_steps=8, tau=0.0):
         """ray_marching + secant (endosurf.py:344-449); n_steps is always 128 there
         (torch.randint(128, 129)). Returns d_pred [N,1] (inf = no hit, 0 = first point occupied)."""
