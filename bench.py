@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=N_RAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward", "frame"])
+    ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["overlap", "fused", "split", "plain"])
     args = ap.parse_args()
 
@@ -153,9 +154,18 @@ def main():
     scene = SyntheticScene(dev, seed=1234 + rank)
     batches = [scene.batch(args.rays) for _ in range(4)]      # resident in HBM before the timed region
     eng = renderer.engine
+    if args.mode == "frame":
+        # cfg5: one 640x512 frame per step, forward only, fixed 2048-ray chunks through one captured hipGraph; the frame's rows
+        # are split across the ranks (no communication; images would be gathered on the host)
+        H = 512
+        rows = H // world
+        frame_rays = scene.frame(H=H, W=640, t=0.5, row0=rank * rows, rows=rows)
+        args.rays = rows * 640
 
     def step(i):
-        if args.mode == "train":
+        if args.mode == "frame":
+            renderer.render_frames(frame_rays, iter_step=1, ray_chunk=2048, perturb_overwrite=False, use_graph=not args.no_graph)
+        elif args.mode == "train":
             trainer.update_learning_rate(i + 1)
             trainer.train_step(batches[i % len(batches)], i + 1)
         else:
@@ -195,12 +205,14 @@ def main():
             roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=tr[0] if tr else None,
                         traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=tr[1] if tr else None, kernel=name,
                         avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
-        out = dict(metric="training rays/sec (1024 rays x 64 samples)" if args.mode == "train" else "forward rays/sec (1024 rays x 64 samples)",
+        out = dict(metric={"train": "training rays/sec (1024 rays x 64 samples)", "forward": "forward rays/sec (1024 rays x 64 samples)",
+                           "frame": "full-frame render rays/sec (640x512, 64 samples, 2048-ray chunks)"}[args.mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   scaling="strong" if args.mode == "frame" else "weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="base_pull.yml nets, %d rays x (32+32) samples per GPU, %s" % (
                        args.rays, "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam"
-                       if args.mode == "train" else "renderer forward only"),
+                       if args.mode == "train" else ("renderer forward only" if args.mode == "forward" else
+                                                     "one 640x512 frame per step, forward only, hipGraph-captured 2048-ray chunks" + (" (eager)" if args.no_graph else ""))),
                        rays_per_gpu=args.rays, samples_per_ray=64, parallelism=f"dp{world}", weights="reference init, torch.manual_seed(0)",
                        algorithmic_gflop_per_ray=dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9,
                                                       train_step=(f_up + 3 * f_core + 2 * 128 * (MAC_D + MAC_S)) / 1e9)),

@@ -201,6 +201,18 @@ class SyntheticScene:
                     mask=torch.ones(n_rays, 1, device=dev), color_mask=torch.ones(n_rays, 1, device=dev))
 
 
+    def frame(self, H: int = 512, W: int = 640, t: float = 0.5, row0: int = 0, rows: int = None) -> torch.Tensor:
+        """Rays [rows, W, 9] of one full frame of the same pinhole camera (no jitter), rows row0..row0+rows."""
+        dev = self.device
+        rows = H - row0 if rows is None else rows
+        v, u = torch.meshgrid(torch.arange(row0, row0 + rows, device=dev, dtype=torch.float32),
+                              torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+        d = torch.stack([(u - 319.5) / 800.0, (v - 255.5) / 800.0, torch.ones_like(u)], -1)
+        d = d / d.norm(dim=-1, keepdim=True)
+        o = torch.tensor([0.0, 0.0, -1.5], device=dev).expand(rows, W, 3)
+        return torch.cat([o, d, torch.zeros(rows, W, 2, device=dev), torch.full((rows, W, 1), float(t), device=dev)], -1).contiguous()
+
+
 class Trainer:
     """zero_grad -> compute_loss -> backward -> (data-parallel gradient all-reduce) -> Adam  (train_step, trainer_endosurf.py:94-104)."""
 
