@@ -59,6 +59,14 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[RTC][NTC], const float* A
     const int lo = lane & 31, hi = lane >> 5;
     float4 b0[PF][NTC], b1[PF][NTC];
     const float4* wl = W + lane;
+    // A-operand addresses: element (k, r) with k = 8G + 2j + hi sits at 512G + 128j + 64hi + (r ^ (4hi) ^ (32(G&1) + 8j)).
+    // The XOR takes 8 values (c = 4(G&1) + j): 8 per-lane registers per row tile, everything else is an immediate offset,
+    // so the MFMA stream carries no address arithmetic (the run-time swizzle cost ~8 % of the loop; tools/micro/chain_micro).
+    int aoff[RTC][8];
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aoff[ri][c] = ((((rt0 + ri) * 32 + lo) ^ (hi << 2)) ^ (8 * c)) + 64 * hi;
 
     auto loadB = [&](float4(&b)[PF][NTC], int g0) {
 #pragma unroll
@@ -67,16 +75,16 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[RTC][NTC], const float* A
             for (int ni = 0; ni < NTC; ++ni)
                 if (!GUARD || g0 + gi < KG) b[gi][ni] = wl[(size_t)((nt0 + ni) * KG + g0 + gi) * 64];
     };
-    auto comp = [&](const float4(&b)[PF][NTC], int g0) {
+    auto comp = [&](const float4(&b)[PF][NTC], int g0) {      // g0 is even at every call site
+        const float* Ag = At + 512 * g0;
 #pragma unroll
         for (int gi = 0; gi < PF; ++gi) {
             if (!GUARD || g0 + gi < KG) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = 8 * (g0 + gi) + 2 * j + hi;
                     float a[RTC];
 #pragma unroll
-                    for (int ri = 0; ri < RTC; ++ri) a[ri] = At[swz(k, (rt0 + ri) * 32 + lo)];
+                    for (int ri = 0; ri < RTC; ++ri) a[ri] = Ag[aoff[ri][4 * (gi & 1) + j] + 512 * gi + 128 * j];
 #pragma unroll
                     for (int ri = 0; ri < RTC; ++ri)
 #pragma unroll

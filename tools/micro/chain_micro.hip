@@ -1,0 +1,122 @@
+// Dev micro-benchmark: the chain kernels' layer loop (gemm_seg<32,2,2>: A from the swizzled LDS tile, B streamed from L2 in
+// packed-fragment order) at 2 workgroups per CU, with the per-layer barriers / epilogue features toggled.
+//   hipcc --offload-arch=gfx950 -O3 -I endosurf_amd/csrc -I include -o tools/micro/chain_micro.bin tools/micro/chain_micro.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "chain_common.h"
+using namespace es;
+
+// candidate inner loop: the swizzled A addresses are 16 per-lane registers (8 XOR patterns x 2 row tiles) + immediates
+template <int KG, int RTC, int NTC>
+__device__ __forceinline__ void gemm_seg2(f32x16 (&acc)[RTC][NTC], const float* At, const float4* __restrict__ W, int rt0, int nt0, int lane) {
+    constexpr int PF = 4;
+    static_assert(KG % (2 * PF) == 0, "micro: full groups only");
+    const int lo = lane & 31, hi = lane >> 5;
+    float4 b0[PF][NTC], b1[PF][NTC];
+    const float4* wl = W + lane;
+    int aoff[RTC][8];
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aoff[ri][c] = ((((rt0 + ri) * 32 + lo) ^ (hi << 2)) ^ (8 * c)) + 64 * hi;
+    auto loadB = [&](float4(&b)[PF][NTC], int g0) {
+#pragma unroll
+        for (int gi = 0; gi < PF; ++gi)
+#pragma unroll
+            for (int ni = 0; ni < NTC; ++ni) b[gi][ni] = wl[(size_t)((nt0 + ni) * KG + g0 + gi) * 64];
+    };
+    auto comp = [&](const float4(&b)[PF][NTC], const float* Ag, int gpar) {      // Ag = At + 512 * g0
+#pragma unroll
+        for (int gi = 0; gi < PF; ++gi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a[RTC];
+#pragma unroll
+                for (int ri = 0; ri < RTC; ++ri) a[ri] = Ag[aoff[ri][4 * ((gi + gpar) & 1) + j] + 512 * gi + 128 * j];
+#pragma unroll
+                for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+                    for (int ni = 0; ni < NTC; ++ni)
+                        acc[ri][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], f4c(b[gi][ni], j), acc[ri][ni], 0, 0, 0);
+            }
+        }
+    };
+    loadB(b0, 0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < KG; g0 += 2 * PF) {
+        loadB(b1, g0 + PF);
+        comp(b0, At + 512 * g0, 0);
+        if (g0 + 2 * PF < KG) loadB(b0, g0 + 2 * PF);
+        comp(b1, At + 512 * (g0 + PF), 0);
+    }
+}
+
+// F bits: 1 = two barriers per layer, 2 = epilogue (bias + relu + LDS store), 4 = epilogue streams the tile to HBM
+template <int F>
+__global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                                  int layers, int nlayer_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < MAIN_FLOATS; i += NTHREADS) mainT[i] = 1e-3f * (i & 31);
+    __syncthreads();
+    const size_t grow0 = (size_t)blockIdx.x * TM;
+    float sink = 0.f;
+#pragma unroll 1
+    for (int l = 0; l < layers; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        if (F & 8) gemm_seg2<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
+        else gemm_seg<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
+        if (F & 1) __syncthreads();
+        if (F & 2) {
+            for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+                const float b = bias[col];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b, 0.f);
+                lds_store_quad(mainT, col, row, v);
+                if (F & 4) g_store_quad(out + (size_t)(l & 7) * gridDim.x * TM * 256, grow0, 256, row, col, v);
+            });
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sink += acc[a][b][r];
+        }
+        if (F & 1) __syncthreads();
+    }
+    if (sink == 123.456f) out[tid] = sink;
+}
+
+template <int F>
+static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers) {
+    hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    const double fl = 2.0 * 64 * 256 * 256 * (double)layers * blocks;
+    printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+}
+
+int main() {
+    float4* W; float *bias, *out;
+    const int blocks = 1024, layers = 64;
+    hipMalloc(&W, (size_t)8 * 8 * 32 * 64 * 16); hipMalloc(&bias, 1024); hipMalloc(&out, (size_t)8 * blocks * TM * 256 * 4);
+    hipMemset(W, 0, (size_t)8 * 8 * 32 * 64 * 16); hipMemset(bias, 0, 1024);
+    run<0>("gemm_seg only (no barriers, no epilogue)", W, bias, out, blocks, layers);
+    run<1>("+ 2 barriers per layer", W, bias, out, blocks, layers);
+    run<3>("+ epilogue (bias, relu, LDS store)", W, bias, out, blocks, layers);
+    run<7>("+ epilogue streams the layer output to HBM", W, bias, out, blocks, layers);
+    run<8>("gemm_seg2 only (precomputed A addresses)", W, bias, out, blocks, layers);
+    run<15>("gemm_seg2 + barriers + epilogue + HBM stream", W, bias, out, blocks, layers);
+    run<3>("same, 512 blocks (one round)", W, bias, out, 512, layers);
+    run<3>("same, 256 blocks (1 workgroup per CU)", W, bias, out, 256, layers);
+    return 0;
+}
