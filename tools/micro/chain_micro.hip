@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, c
     for (int l = 0; l < layers; ++l) {
         f32x16 acc[2][2];
         acc_zero(acc);
-        if (F & 8) gemm_seg2<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
+        if (F & 16) gemm_seg<32, 2, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
+        else if (F & 8) gemm_seg2<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
         else gemm_seg<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
         if (F & 1) __syncthreads();
         if (F & 2) {
@@ -116,6 +117,10 @@ int main() {
     run<7>("+ epilogue streams the layer output to HBM", W, bias, out, blocks, layers);
     run<8>("gemm_seg2 only (precomputed A addresses)", W, bias, out, blocks, layers);
     run<15>("gemm_seg2 + barriers + epilogue + HBM stream", W, bias, out, blocks, layers);
+    run<0>("library gemm_seg PF=4", W, bias, out, blocks, layers);
+    run<16>("library gemm_seg PF=2", W, bias, out, blocks, layers);
+    run<16 + 7>("library gemm_seg PF=2 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
+    run<7>("library gemm_seg PF=4 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
     run<3>("same, 512 blocks (one round)", W, bias, out, 512, layers);
     run<3>("same, 256 blocks (1 workgroup per CU)", W, bias, out, 256, layers);
     return 0;
