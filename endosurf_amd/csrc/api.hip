@@ -18,6 +18,8 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st);
 int train_loss(const LossArgs& a, hipStream_t st);
+int adam_step(float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps, float step_size,
+              float bc2_sqrt, float grad_scale, const float* g_extra, long long extra_index, hipStream_t st);
 static_assert(sizeof(es_loss_args) == sizeof(LossArgs), "es_loss_args must mirror es::LossArgs");
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
@@ -199,6 +201,14 @@ int es_train_loss(const es_loss_args* a, void* stream) {
                a->depth_gt && a->mask && a->cmask && a->valid_sn, "es_train_loss inputs");
     ES_REQUIRE(a->terms && a->g_color && a->g_depth && a->g_eik && a->g_aux_sdf && a->g_aux_go, "es_train_loss outputs");
     return train_loss(*reinterpret_cast<const LossArgs*>(a), (hipStream_t)stream);
+}
+
+int es_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float beta1, float beta2, float eps,
+                 float step_size, float bc2_sqrt, float grad_scale, const float* g_extra, long long extra_index, void* stream) {
+    ES_REQUIRE(params && grad && exp_avg && exp_avg_sq && n >= 0, "es_adam_step buffers");
+    ES_REQUIRE(g_extra == nullptr || (extra_index >= 0 && extra_index < n), "es_adam_step extra gradient index");
+    return adam_step(params, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, g_extra, extra_index,
+                     (hipStream_t)stream);
 }
 
 }  // extern "C"

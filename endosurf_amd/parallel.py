@@ -54,6 +54,14 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group=None):
     unflatten_to_grads(flat, params)
 
 
+def allreduce_flat(flat: torch.Tensor, group=None) -> int:
+    """Sum a flat gradient bucket across ranks in place (one collective); returns the world size (1 if not distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return dist.get_world_size(group)
+
+
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None):
     """Make every rank start from rank ``src``'s weights (one flat broadcast)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

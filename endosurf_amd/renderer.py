@@ -210,6 +210,8 @@ class _PackFn(torch.autograd.Function):
         if model is not None:
             model._pack_cache = None
         dflat = ctx.eng.weightnorm_backward(ctx.flat, dweff.contiguous(), ctx.use_deform)
+        if model is not None:
+            model._flat_grad = dflat          # the parameters' .grad are views of this buffer (used by trainer.FlatAdam)
         return (None, None, *[dflat[off:off + n].view(shape) for off, n, shape in ctx.slots])
 
 
@@ -310,6 +312,8 @@ class EndoSurfRenderer(nn.Module):
         self.engine = Engine(self.device)          # raises if not an AMD GPU / library missing: no fallback
         self.model = EndoSurfNet(net_cfg, self.device)
         self.model._pack_cache = None
+        self.model._flat_grad = None
+        self.model._epoch = 0            # bumped by in-place updates that bypass torch's version counters (trainer.FlatAdam)
         self.anneal_end = render_cfg["anneal_end"]
         self.n_samples = render_cfg["n_samples"]
         self.perturb = render_cfg["perturb"]
@@ -339,7 +343,7 @@ class EndoSurfRenderer(nn.Module):
         m = self.model
         plist = [p for _, p in m.ordered_params()]
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
-        key = (tuple(p._version for p in plist), want_grad)
+        key = ((tuple(p._version for p in plist), m._epoch), want_grad)
         c = m._pack_cache
         if c is not None and c[0] == key:
             return c[1], c[2]
@@ -527,7 +531,7 @@ class EndoSurfRenderer(nn.Module):
                     c, d, nm = chunk_forward(flat[i:i + C])
                     out["color"][i:i + C], out["depth"][i:i + C], out["normal"][i:i + C] = c, d, nm
                 return out
-            key = (C, int(iter_step), perturb_overwrite, weff.data_ptr(), tuple(p._version for p in self.parameters()))
+            key = (C, int(iter_step), perturb_overwrite, weff.data_ptr(), tuple(p._version for p in self.parameters()), self.model._epoch)
             g = getattr(self, "_frame_graph", None)
             if g is None or g["key"] != key:
                 static_in = self.engine.empty(C, 9)

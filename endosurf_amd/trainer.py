@@ -213,21 +213,88 @@ class SyntheticScene:
         return torch.cat([o, d, torch.zeros(rows, W, 2, device=dev), torch.full((rows, W, 1), float(t), device=dev)], -1).contiguous()
 
 
+class FlatAdam:
+    """torch.optim.Adam with the reference's settings (trainer_endosurf.py:65-71: one group, defaults) as ONE kernel launch over
+    the renderer's flat parameter buffer (es_adam_step).  The gradient is the flat buffer produced by es_weightnorm_backward
+    (the parameters' ``.grad`` are views of it) plus the scalar variance gradient; if gradients were accumulated or produced
+    some other way they are gathered from ``.grad`` first.  ``param_groups[0]['lr']`` is read at every step like torch's."""
+
+    def __init__(self, renderer, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model, self.eng = renderer.model, renderer.engine
+        self.flat = self.model._flat
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps)]
+        self.step_count = 0
+        self._named = [(self.model._layout[k][0], p) for k, p in self.model.ordered_params()]
+        self._var = self.model.deviation_network.variance
+        self._var_off = int(self.model._layout["deviation_network.variance"][0])
+        self._all = [p for _, p in self._named] + [self._var]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self._all:
+            p.grad = None
+        self.model._flat_grad = None
+
+    def flat_grad(self, include_variance: bool = False) -> torch.Tensor:
+        """The gradient in flat-buffer layout (variance slot filled only if ``include_variance``)."""
+        g = self.model._flat_grad
+        off0, p0 = self._named[0]
+        offl, pl = self._named[-1]
+        ok = (g is not None and p0.grad is not None and pl.grad is not None and p0.grad.data_ptr() == g.data_ptr() + 4 * off0
+              and pl.grad.data_ptr() == g.data_ptr() + 4 * offl)
+        if not ok:                      # accumulated / foreign gradients: gather .grad into a fresh flat buffer
+            g = torch.zeros_like(self.flat)
+            with torch.no_grad():
+                pairs = [(g[off:off + p.numel()].view(p.shape), p.grad) for off, p in self._named if p.grad is not None]
+                if pairs:
+                    torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+        if include_variance and self._var.grad is not None:
+            with torch.no_grad():
+                g[self._var_off:self._var_off + 1].copy_(self._var.grad.reshape(1))
+        return g
+
+    def step(self, grad: torch.Tensor = None, grad_scale: float = 1.0, variance_in_grad: bool = False):
+        from . import _lib
+        g = self.flat_grad() if grad is None else grad
+        gv = None if (variance_in_grad or self._var.grad is None) else self._var.grad
+        self.step_count += 1
+        pg = self.param_groups[0]
+        b1, b2 = pg["betas"]
+        step_size = pg["lr"] / (1.0 - b1 ** self.step_count)
+        bc2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
+        _lib.check(self.eng.lib.es_adam_step(_lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                             self.flat.numel(), b1, b2, pg["eps"], step_size, bc2_sqrt, float(grad_scale),
+                                             _lib.ptr(gv) if gv is not None else None, self._var_off, _lib.stream_ptr()), "es_adam_step")
+        self.model._epoch += 1            # parameters changed behind torch's version counters: invalidate the packed weights
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
 class Trainer:
     """zero_grad -> compute_loss -> backward -> (data-parallel gradient all-reduce) -> Adam  (train_step, trainer_endosurf.py:94-104)."""
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
                  loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
-                 schedule: str = None):
+                 schedule: str = None, flat_adam: bool = True):
         self.renderer = renderer
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
         # Adam with the reference's defaults (trainer_endosurf.py:70); on the GPU the single-kernel "fused" implementation
         # of the same update is used (81 parameter tensors -> one launch)
-        try:
-            self.optimizer = torch.optim.Adam(params=self.params, lr=lr, fused=self.params[0].is_cuda)
-        except (TypeError, RuntimeError):
-            self.optimizer = torch.optim.Adam(params=self.params, lr=lr)
+        if flat_adam:
+            self.optimizer = FlatAdam(renderer, lr=lr)          # the same update as one launch over the flat parameter buffer
+        else:
+            try:
+                self.optimizer = torch.optim.Adam(params=self.params, lr=lr, fused=self.params[0].is_cuda)
+            except (TypeError, RuntimeError):
+                self.optimizer = torch.optim.Adam(params=self.params, lr=lr)
         self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
         self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
         self.data_parallel = data_parallel
@@ -245,6 +312,15 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss, terms, ret = self.loss_fn(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
         loss.backward()
+        if isinstance(self.optimizer, FlatAdam):
+            if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update
+                from .parallel import allreduce_flat
+                g = self.optimizer.flat_grad(include_variance=True)
+                world = allreduce_flat(g)
+                self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
+            else:
+                self.optimizer.step()
+            return loss.detach(), terms, ret
         if self.data_parallel:
             from .parallel import allreduce_gradients
             allreduce_gradients(self.params)

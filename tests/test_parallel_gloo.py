@@ -56,3 +56,29 @@ def test_flat_bucket_roundtrip():
     assert flat.tolist() == [0, 1, 2, 3, 4, 5, 0, 0, 0, 0]
     parallel.unflatten_to_grads(flat + 1, ps)
     assert ps[0].grad.tolist() == [[1, 2, 3], [4, 5, 6]] and ps[1].grad.tolist() == [1, 1, 1, 1]
+
+
+def _flat_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    from endosurf_amd import parallel
+    parallel.init_distributed("gloo")
+    g = torch.full((1000,), float(rank + 1))
+    w = parallel.allreduce_flat(g)
+    q.put((rank, w, float(g[0]), float(g[-1])))
+    torch.distributed.destroy_process_group()
+
+
+def test_allreduce_flat_sums_one_bucket():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000) + 7
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, 2, 3.0, 3.0), (1, 2, 3.0, 3.0)]
