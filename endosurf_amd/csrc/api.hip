@@ -18,6 +18,8 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st);
 int train_loss(const LossArgs& a, hipStream_t st);
+int train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
+                     float* x, float* t, unsigned char* valid, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps, float step_size,
               float bc2_sqrt, float grad_scale, const float* g_extra, long long extra_index, hipStream_t st);
 static_assert(sizeof(es_loss_args) == sizeof(LossArgs), "es_loss_args must mirror es::LossArgs");
@@ -201,6 +203,12 @@ int es_train_loss(const es_loss_args* a, void* stream) {
                a->depth_gt && a->mask && a->cmask && a->valid_sn, "es_train_loss inputs");
     ES_REQUIRE(a->terms && a->g_color && a->g_depth && a->g_eik && a->g_aux_sdf && a->g_aux_go, "es_train_loss outputs");
     return train_loss(*reinterpret_cast<const LossArgs*>(a), (hipStream_t)stream);
+}
+
+int es_train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
+                        float* x, float* t, unsigned char* valid, void* stream) {
+    ES_REQUIRE(rays && depth_gt && mask && d_i && u && x && t && valid && N >= 0, "es_train_aux_points buffers");
+    return train_aux_points(rays, depth_gt, mask, d_i, u, rad, N, x, t, valid, (hipStream_t)stream);
 }
 
 int es_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float beta1, float beta2, float eps,

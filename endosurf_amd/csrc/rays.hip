@@ -424,6 +424,34 @@ __global__ __launch_bounds__(256) void k_march_finish(const float* __restrict__ 
     d_out[i] = v;
 }
 
+// The 3N auxiliary points of a training step in one launch (instead of ~28 element-wise torch kernels):
+//   rows [0,N):   errorondepth points  o + d_z * depth_gt                          (endosurf.py:297-300)
+//   rows [N,2N):  surface points       o + d_z * d_i  (d_i = 0 where the ray has no valid hit)   (endosurf.py:325-329)
+//   rows [2N,3N): their neighbours     surface + (u - 0.5) * rad                    (endosurf.py:331-332)
+// valid[i] = isfinite(d_i) && d_i != 0 && mask == 1  (endosurf.py:323);  t = rays[:, 8] for every block of rows.
+__global__ __launch_bounds__(256) void k_train_aux_points(const float* __restrict__ rays, const float* __restrict__ depth_gt,
+                                                          const float* __restrict__ mask, const float* __restrict__ d_i,
+                                                          const float* __restrict__ u, float rad, int N, float* __restrict__ x,
+                                                          float* __restrict__ t, unsigned char* __restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* r = rays + 9 * (size_t)i;
+    const float inv = r[5] + 1e-6f;
+    const float dz[3] = {r[3] / inv, r[4] / inv, r[5] / inv};
+    const float di = d_i[i];
+    const bool ok = !__builtin_isinf(di) && !__builtin_isnan(di) && di != 0.f && mask[i] == 1.f;
+    const float ds = ok ? di : 0.f, dg = depth_gt[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ps = r[c] + ds * dz[c];
+        x[3 * (size_t)i + c] = r[c] + dz[c] * dg;
+        x[3 * (size_t)(N + i) + c] = ps;
+        x[3 * (size_t)(2 * N + i) + c] = ps + (u[3 * (size_t)i + c] - 0.5f) * rad;
+    }
+    t[i] = r[8]; t[N + i] = r[8]; t[2 * N + i] = r[8];
+    valid[i] = ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 ray_grid(int N) { return dim3((N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
@@ -474,6 +502,12 @@ int secant_update(const float* sdf_mid, int N, float tau, float* state, float* d
     if (N <= 0) return ST_OK;
     hipLaunchKernelGGL(k_secant_update, dim3((N + 255) / 256), dim3(256), 0, st, sdf_mid, N, tau, state, d_pred);
     return hip_last("secant_update");
+}
+int train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
+                     float* x, float* t, unsigned char* valid, hipStream_t st) {
+    if (N <= 0) return ST_OK;
+    hipLaunchKernelGGL(k_train_aux_points, dim3((N + 255) / 256), dim3(256), 0, st, rays, depth_gt, mask, d_i, u, rad, N, x, t, valid);
+    return hip_last("train_aux_points");
 }
 int march_finish(const float* d_pred, const int* flags, int N, float* d_out, hipStream_t st) {
     if (N <= 0) return ST_OK;

@@ -408,7 +408,7 @@ class EndoSurfRenderer(nn.Module):
             "weights": ret["weights"],
             "weight_max": ret["weight_max"],
             "cdf": ret["cdf"],
-            "s_val": ret["s_val"].reshape(1, 1).expand(n_rays, n_samples).mean(dim=-1, keepdim=True),
+            "s_val": ret["s_val"].reshape(1, 1).expand(n_rays, 1),      # mean over the samples of one shared value (endosurf.py:131)
         }
 
     def render_core(self, rays_o, rays_d, time, z_vals, sample_dist, cos_anneal_ratio=0.0, eval=False, _rays=None, _aux=None):
@@ -427,9 +427,9 @@ class EndoSurfRenderer(nn.Module):
             weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), self._flags(weff), aux_x, aux_t)
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
-        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        s_val = torch.exp(var * -10.0).clip(1e-6, 1e6)          # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
         return {"color_map": color, "depth_map": depth, "gradients_o": g_o, "gradient_o_error": eik, "cdf": cdf,
-                "weights": weights, "weight_max": wmax, "s_val": 1.0 / inv_s, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
+                "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
 
     # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
     def _point_eval(self, x, t, dirs=None):
@@ -500,6 +500,18 @@ class EndoSurfRenderer(nn.Module):
             u = u_neigh if u_neigh is not None else torch.rand(N, 3, device=self.device)
             p_neig = p_surf + (u.to(torch.float32) - 0.5) * neighbour_rad
             return torch.cat([p_surf, p_neig], 0).contiguous(), torch.cat([time, time], 0).contiguous(), valid
+
+    def _train_aux_points(self, rays, depth_gt, mask, d_i, neighbour_rad, u_neigh=None):
+        """(x [3N,3], t [3N], valid [N] bool): the points of _eod_points and _sn_points (same arithmetic) in one launch."""
+        N = rays.shape[0]
+        f = lambda a: a.detach().to(torch.float32).contiguous()
+        u = f(u_neigh) if u_neigh is not None else torch.rand(N, 3, device=self.device)
+        x, t = self.engine.empty(3 * N, 3), self.engine.empty(3 * N)
+        valid = self.engine.empty(N, dtype=torch.bool)
+        _lib.check(self.engine.lib.es_train_aux_points(_lib.ptr(rays), _lib.ptr(f(depth_gt)), _lib.ptr(f(mask)), _lib.ptr(f(d_i)), _lib.ptr(u),
+                                                       float(neighbour_rad), N, _lib.ptr(x), _lib.ptr(t), _lib.ptr(valid), _lib.stream_ptr()),
+                   "es_train_aux_points")
+        return x, t, valid
 
     def _sn_loss(self, g, valid):
         N = valid.shape[0]

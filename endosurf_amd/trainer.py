@@ -39,7 +39,6 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
     N = rays.shape[0]
     renderer._weights()          # weight-norm + packing once per step, with the autograd node (ray marching below is no_grad)
-    eod_pts, time = renderer._eod_points(rays, depth_gt)
     # The 128-proposal ray-marching query fills the GPU; the 8 secant iterations after it and the hierarchical sampling
     # (coarse query + 3 dependent 8-sample queries) are independent chains of small, latency-bound launches: run the sampling
     # on a side stream WHILE the main stream iterates the secant (two throughput-bound kernels would only slow each other)
@@ -52,11 +51,10 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     with torch.cuda.stream(side):
         z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
     d_i = renderer._march_refine(ms)
-    sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh, d_i=d_i)
+    aux_x, aux_t, valid_sn = renderer._train_aux_points(rays, depth_gt, mask_gt, d_i, surf_neig_rad, u_neigh)    # one launch
+    eod_pts = aux_x[:N]
     main.wait_stream(side)
     z.record_stream(main)
-    aux_x = torch.cat([eod_pts, sn_pts], 0)
-    aux_t = torch.cat([time, sn_t], 0)
     if split_aux:
         # the 3N auxiliary points as their own (small) launches on the side stream, concurrent with the render's: they fill
         # the slots the render's kernels free at the end of their last full round instead of adding a nearly empty round
@@ -136,7 +134,7 @@ class _LossFn(torch.autograd.Function):
             raise ValueError("es_train_loss expects per-ray masks [N,1] and 3N auxiliary points")
         f = lambda t: t.detach().to(torch.float32).contiguous()
         ins = [f(color_map), f(depth_map), f(eik).reshape(1), f(aux_sdf), f(aux_go), f(rays), f(eod_pts), f(color_gt), f(depth_gt), f(mask),
-               f(cmask), valid_sn.to(torch.uint8).contiguous()]
+               f(cmask), (valid_sn.view(torch.uint8) if valid_sn.dtype == torch.bool else valid_sn.to(torch.uint8)).contiguous()]
         terms = eng.empty(8)
         grads = [eng.empty(N, 3), eng.empty(N, 1), eng.empty(1), eng.empty(3 * N, 1), eng.empty(3 * N, 3)]
         a = _lib.es_loss_args()
