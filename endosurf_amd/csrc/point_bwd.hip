@@ -62,7 +62,7 @@ __device__ __forceinline__ float enc3_adjoint_g(const float* __restrict__ adj, i
 // -------------------------------------------------------------------------------------------------------------
 // lean carve (activation tile + 3.75 KB): the adjoint of the input's small part accumulates in HBM (WS_C_SBAR), not in LDS
 constexpr int CBWD_LDS_BYTES = (MAIN_FLOATS + 960) * 4;   // 69 376 B
-__global__ __launch_bounds__(NTHREADS, 2) void k_color_bwd(BwdArgs a) {
+__device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* scr = lds + MAIN_FLOATS;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_color_bwd(BwdArgs a) {
     float* td = scr + 768;     // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * TM;
+    const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
     const bool deform = a.flags & PF_DEFORM;
     const size_t Mp = (size_t)a.L.Mp;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_color_bwd(BwdArgs a) {
 // -------------------------------------------------------------------------------------------------------------
 // lean carve: activation tile | 40-row auxiliary tile | 640 floats of per-row data  => two workgroups per CU
 constexpr int SBWD_LDS_BYTES = (MAIN_FLOATS + 40 * TM + 640) * 4;   // 78 336 B
-__global__ __launch_bounds__(NTHREADS, 2) void k_sdf_bwd(BwdArgs a) {
+__device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sdf_bwd(BwdArgs a) {
     float* tx = scr + 448;     // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * TM;
+    const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
     const bool deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
     const size_t Mp = (size_t)a.L.Mp;
@@ -419,13 +419,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sdf_bwd(BwdArgs a) {
 // LDS: activation tile + 768 B only => two workgroups per CU (2 waves per SIMD): one workgroup's epilogue / barrier
 // phases overlap the other's MFMA stream.
 constexpr int DBWD_LDS_BYTES = (MAIN_FLOATS + 192) * 4;
-__global__ __launch_bounds__(NTHREADS, 2) void k_deform_bwd(BwdArgs a) {
+__device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* a8 = lds + MAIN_FLOATS;   // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = blockIdx.x * 16;
+    const int pt0 = tile * 16;
     const size_t grow0 = (size_t)pt0 * 4;
     const size_t rows4 = (size_t)a.L.Mp * 4;
 
@@ -480,24 +480,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_deform_bwd(BwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
-                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st) {
+// Two-segment launches as in point_fwd.hip: the tail's two dependent stages ride in the halves of the main deformation launch
+//   colour_bwd(main) | sdf_bwd(main) | sdf_bwd(tail) + deform_bwd(main, 1st half) | deform_bwd(tail) + deform_bwd(main, 2nd half)
+enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM };
+template <int B>
+__device__ __forceinline__ void bwd_body(const BwdArgs& a, int tile) {
+    if constexpr (B == BB_COLOR) color_bwd_tile(a, tile);
+    else if constexpr (B == BB_SDF) sdf_bwd_tile(a, tile);
+    else if constexpr (B == BB_DEFORM) deform_bwd_tile(a, tile);
+}
+template <int B0, int B1>
+__global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, int t0, int t1) {
+    if constexpr (B0 != BB_NONE) {
+        if ((int)blockIdx.x < n0) { bwd_body<B0>(a, t0 + blockIdx.x); return; }
+    }
+    bwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
+}
+constexpr int bwd_lds(int b) { return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : 0)); }
+template <int B0, int B1>
+static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
+    constexpr int lds = bwd_lds(B0) > bwd_lds(B1) ? bwd_lds(B0) : bwd_lds(B1);
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_color_bwd, CBWD_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_bwd, SBWD_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_deform_bwd, DBWD_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_point_bwd<B0, B1>, lds)) return e;
         attr_done = true;
     }
+    if (n0 + n1 <= 0) return ST_OK;
+    hipLaunchKernelGGL((k_point_bwd<B0, B1>), dim3(n0 + n1), dim3(NTHREADS), lds, st, a, n0, t0, t1);
+    return ST_OK;
+}
+
+int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st) {
     if (src.M <= 0) return ST_OK;
     BwdArgs a;
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags; a.d_sdf = d_sdf; a.d_go = d_go; a.d_rgb = d_rgb;
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); hipLaunchKernelGGL(k_color_bwd, dim3(Mcp / TM), dim3(NTHREADS), CBWD_LDS_BYTES, st, a); }
-    { ScopedTimer tm(KID_SDF_BWD, src.M, st); hipLaunchKernelGGL(k_sdf_bwd, dim3(Mp / TM), dim3(NTHREADS), SBWD_LDS_BYTES, st, a); }
-    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); hipLaunchKernelGGL(k_deform_bwd, dim3(Mp / 16), dim3(NTHREADS), DBWD_LDS_BYTES, st, a); }
+    const bool deform = flags & PF_DEFORM;
+    if (deform && aux_tail(flags, a.M_color, src.M)) {
+        const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
+        { ScopedTimer tm(KID_COLOR_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_DEFORM_BWD, Mc, st);
+          if (int e = launch_bwd<BB_SDF, BB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, h, 0, st)) return e;
+          if (int e = launch_bwd<BB_DEFORM, BB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, nd - h, h, st)) return e; }
+        return hip_last("point_backward_chains");
+    }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
+    { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+    if (deform) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, Mp / 16, 0, st)) return e; }
     return hip_last("point_backward_chains");
 }
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws +
 // -------------------------------------------------------------------------------------------------------------
 // deformation network, value + 3 tangents.  Tile = 16 points = 64 rows (row 4p + c).
 // Two workgroups per CU (lean LDS carve, <= 256 registers): one workgroup's epilogue/barrier phases hide under the other's MFMAs.
-__global__ __launch_bounds__(NTHREADS, 2) void k_deform_fwd(FwdArgs a) {
+__device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_deform_fwd(FwdArgs a) {
     float* red = aux;        // [4][3][64]: the encoding rows are dead after layer 3's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = blockIdx.x * 16;
+    const int pt0 = tile * 16;
     const size_t grow0 = (size_t)pt0 * 4;
     const bool save = a.flags & PF_SAVE;
     const size_t rows4 = (size_t)a.L.Mp * 4;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_deform_fwd(FwdArgs a) {
 
 // -------------------------------------------------------------------------------------------------------------
 // SDF network: value pass + reverse sweep.  Tile = 64 points.
-__global__ __launch_bounds__(NTHREADS, 2) void k_sdf_fwd(FwdArgs a) {
+__device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;        // 56 rows: enc6(x_c) (40 used), later the adjoint of the encoding (40 used)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sdf_fwd(FwdArgs a) {
     float* gcv = mainT;       // [3][64]     (activation tile is dead after the last reverse GEMM)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * TM;
+    const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
     const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
     const size_t Mp = (size_t)a.L.Mp;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sdf_fwd(FwdArgs a) {
 // colour network.  Tile = 64 points.  Lean LDS carve (activation tile + 5 KB): the 93-wide small part of the input is
 // staged through the activation tile itself (and re-staged from HBM at the skip layer), so two workgroups fit per CU.
 constexpr int CFWD_LDS_BYTES = (MAIN_FLOATS + 1344) * 4;   // 70 912 B
-__global__ __launch_bounds__(NTHREADS, 2) void k_color_fwd(FwdArgs a) {
+__device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* scr = lds + MAIN_FLOATS;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_color_fwd(FwdArgs a) {
     float* red = scr + 576;   // [4][3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * TM;
+    const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
     const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM;
     const size_t Mp = (size_t)a.L.Mp;
@@ -403,23 +403,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_color_fwd(FwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st) {
+// One launch = two segments of tiles, possibly of different networks: blocks [0, n0) run body B0 on tiles t0.., the rest run
+// body B1 on tiles t1...  Used for the short colour-less tail of a training batch (errorondepth / surface-neighbour points):
+// launched with its own network's main tiles it adds a nearly empty third round of the 512 workgroup slots to the SDF
+// kernels (1024 + 48 tiles), which costs a full tile time.  Every main launch of this workload is a whole number of rounds,
+// so extra tiles always cost something -- least inside a launch of MANY short rounds: the tail's two dependent stages
+// (deform, then SDF) are therefore mixed into the two halves of the 8-round deformation launch of the main tiles.
+enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR };
+template <int B>
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
+    if constexpr (B == FB_DEFORM) deform_fwd_tile(a, tile);
+    else if constexpr (B == FB_SDF) sdf_fwd_tile(a, tile);
+    else if constexpr (B == FB_COLOR) color_fwd_tile(a, tile);
+}
+template <int B0, int B1>
+__global__ __launch_bounds__(NTHREADS, 2) void k_point_fwd(FwdArgs a, int n0, int t0, int t1) {
+    if constexpr (B0 != FB_NONE) {
+        if ((int)blockIdx.x < n0) { fwd_body<B0>(a, t0 + blockIdx.x); return; }
+    }
+    fwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
+}
+constexpr int fwd_lds(int b) { return b == FB_COLOR ? CFWD_LDS_BYTES : (b == FB_NONE ? 0 : LEAN_LDS_BYTES); }
+template <int B0, int B1>
+static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
+    constexpr int lds = fwd_lds(B0) > fwd_lds(B1) ? fwd_lds(B0) : fwd_lds(B1);
     static bool attr_done = false;
     if (!attr_done) {
-        if (int e = allow_big_lds(k_deform_fwd, LEAN_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd, LEAN_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_color_fwd, CFWD_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_point_fwd<B0, B1>, lds)) return e;
         attr_done = true;
     }
+    if (n0 + n1 <= 0) return ST_OK;
+    hipLaunchKernelGGL((k_point_fwd<B0, B1>), dim3(n0 + n1), dim3(NTHREADS), lds, st, a, n0, t0, t1);
+    return ST_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st) {
     if (src.M <= 0) return ST_OK;
     FwdArgs a;
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
     a.L = ws_layout(src.M, flags); a.flags = flags;
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
-    if (flags & PF_DEFORM) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); hipLaunchKernelGGL(k_deform_fwd, dim3(Mp / 16), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
-    { ScopedTimer tm(KID_SDF_FWD, src.M, st); hipLaunchKernelGGL(k_sdf_fwd, dim3(Mp / TM), dim3(NTHREADS), LEAN_LDS_BYTES, st, a); }
-    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); hipLaunchKernelGGL(k_color_fwd, dim3(Mcp / TM), dim3(NTHREADS), CFWD_LDS_BYTES, st, a); }
+    const bool deform = flags & PF_DEFORM;
+    if (deform && aux_tail(flags, a.M_color, src.M)) {
+        // main tiles [0, Mc), colour-less tail [Mc, Mp):
+        //   deform(tail) + deform(main, 1st half) | sdf(tail) + deform(main, 2nd half) | sdf(main) | colour(main)
+        const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
+        { ScopedTimer tm(KID_DEFORM_FWD, Mc, st);
+          if (int e = launch_fwd<FB_DEFORM, FB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, h, 0, st)) return e;
+          if (int e = launch_fwd<FB_SDF, FB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, nd - h, h, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        return hip_last("point_forward");
+    }
+    if (deform) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mp / 16, 0, st)) return e; }
+    { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+    if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
     return hip_last("point_forward");
 }
 

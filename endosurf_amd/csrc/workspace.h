@@ -6,6 +6,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 namespace es {
 
@@ -71,6 +72,12 @@ inline WsLayout ws_layout(int M, int flags) {
     for (int i = 0; i < WS_COUNT; ++i) { L.off[i] = o; o += (sz[i] + 63) / 64 * 64; }   // keep every buffer 256-B aligned
     L.off[WS_COUNT] = o;
     return L;
+}
+
+// a colour-less tail [m_color, M) behind a tile-aligned main part (the fused training batch): see point_fwd.hip
+inline bool aux_tail(int flags, int m_color, int M) {
+    static const bool off = getenv("ES_NO_TAIL_MIX") != nullptr;
+    return !off && (flags & PF_COLOR) && m_color > 0 && m_color < M && m_color % 64 == 0;
 }
 
 }  // namespace es
