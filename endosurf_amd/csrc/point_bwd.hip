@@ -523,7 +523,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
         const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
         { ScopedTimer tm(KID_COLOR_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
         { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
-        { ScopedTimer tm(KID_DEFORM_BWD, Mc, st);
+        { ScopedTimer tm(KID_DEFORM_BWD, src.M, st);      // all deformation tiles (+ the tail's SDF tiles, not counted as work)
           if (int e = launch_bwd<BB_SDF, BB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, h, 0, st)) return e;
           if (int e = launch_bwd<BB_DEFORM, BB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, nd - h, h, st)) return e; }
         return hip_last("point_backward_chains");

@@ -450,7 +450,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         // main tiles [0, Mc), colour-less tail [Mc, Mp):
         //   deform(tail) + deform(main, 1st half) | sdf(tail) + deform(main, 2nd half) | sdf(main) | colour(main)
         const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
-        { ScopedTimer tm(KID_DEFORM_FWD, Mc, st);
+        { ScopedTimer tm(KID_DEFORM_FWD, src.M, st);      // all deformation tiles (+ the tail's SDF tiles, not counted as work)
           if (int e = launch_fwd<FB_DEFORM, FB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, h, 0, st)) return e;
           if (int e = launch_fwd<FB_SDF, FB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, nd - h, h, st)) return e; }
         { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }

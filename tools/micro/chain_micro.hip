@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_seg2(f32x16 (&acc)[RTC][NTC], const float* 
 // F bits: 1 = two barriers per layer, 2 = epilogue (bias + relu + LDS store), 4 = epilogue streams the tile to HBM
 template <int F>
 __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
-                                                  int layers, int nlayer_w) {
+                                                  int layers, int nlayer_w, int stag) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,6 +63,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, c
     __syncthreads();
     const size_t grow0 = (size_t)blockIdx.x * TM;
     float sink = 0.f;
+    if (F & 32) {      // stagger the two co-resident workgroups by about half a layer so that epilogues and GEMMs interleave
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1) { for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127); }
+    }
 #pragma unroll 1
     for (int l = 0; l < layers; ++l) {
         f32x16 acc[2][2];
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, c
 }
 
 template <int F>
-static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers) {
+static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers, int stag = 2) {
     hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8, stag);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8, stag);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
     const double fl = 2.0 * 64 * 256 * 256 * (double)layers * blocks;
@@ -121,6 +126,10 @@ int main() {
     run<16>("library gemm_seg PF=2", W, bias, out, blocks, layers);
     run<16 + 7>("library gemm_seg PF=2 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
     run<7>("library gemm_seg PF=4 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
+    run<32 + 7>("PF=2 full + stagger 1", W, bias, out, blocks, layers, 1);
+    run<32 + 7>("PF=2 full + stagger 2", W, bias, out, blocks, layers, 2);
+    run<32 + 7>("PF=2 full + stagger 3", W, bias, out, blocks, layers, 3);
+    run<32 + 7>("PF=2 full + stagger 4", W, bias, out, blocks, layers, 4);
     run<3>("same, 512 blocks (one round)", W, bias, out, 512, layers);
     run<3>("same, 256 blocks (1 workgroup per CU)", W, bias, out, 256, layers);
     return 0;

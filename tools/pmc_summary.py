@@ -26,6 +26,11 @@ def agg(d):
     return acc
 
 
+# the chain kernels are instantiations of two dispatcher templates (point_fwd.hip / point_bwd.hip): <B0, B1> = (tail body, main body)
+LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<1, 1>": "k_deform_fwd", "k_point_fwd<2, 1>": "k_deform_fwd",
+           "k_point_fwd<0, 2>": "k_sdf_fwd", "k_point_fwd<0, 3>": "k_color_fwd", "k_point_bwd<0, 1>": "k_color_bwd",
+           "k_point_bwd<0, 2>": "k_sdf_bwd", "k_point_bwd<0, 3>": "k_deform_bwd", "k_point_bwd<2, 3>": "k_deform_bwd",
+           "k_point_bwd<3, 3>": "k_deform_bwd"}
 a, f, w = agg(d_sq), agg(d_f), agg(d_w)
 out = []
 for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
@@ -36,7 +41,7 @@ for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
     cyc = m("GRBM_GUI_ACTIVE") / 8
     fetch = st.mean(f.get(key, {}).get("FETCH_SIZE", [float("nan")])) * 1024 * 2
     write = st.mean(w.get(key, {}).get("WRITE_SIZE", [float("nan")])) * 1024
-    out.append(dict(kernel=key[0], grid_threads=key[1], launches=len(c["GRBM_GUI_ACTIVE"]), cycles=round(cyc),
+    out.append(dict(kernel=key[0], logical=LOGICAL.get(key[0], key[0].split("<")[0]), grid_threads=key[1], launches=len(c["GRBM_GUI_ACTIVE"]), cycles=round(cyc),
                     mfma_util=round(m("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * cyc), 4),
                     wait_any=round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 4), wait_inst_any=round(m("SQ_WAIT_INST_ANY") / m("SQ_WAVE_CYCLES"), 4),
                     hbm_fetch_bytes=round(fetch), hbm_write_bytes=round(write), hbm_bytes=round(fetch + write)))
