@@ -192,7 +192,26 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    timing = kernel_timing(eng, step, args.warmup + args.steps, 3) if rank == 0 or world == 1 else {}
+    # the same step with ray marching's early exit disabled (all 128 proposals of every ray evaluated, as the reference does):
+    # the data-independent worst case, reported next to the headline value
+    worst = None
+    if args.mode == "train" and eng.march_block:
+        blk, eng.march_block = eng.march_block, 0
+        nw = max(3, args.steps // 3)
+        step(args.warmup + args.steps)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(nw):
+            step(args.warmup + args.steps + 1 + i)
+        barrier()
+        dtw = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dtw = float(t.item())
+        eng.march_block = blk
+        worst = dict(ms_per_step=dtw / nw * 1e3, value=world * args.rays * nw / dtw, steps=nw)
+    timing = kernel_timing(eng, step, args.warmup + args.steps + 64, 3) if rank == 0 or world == 1 else {}
     ms = dt / args.steps * 1e3
     value = world * args.rays * args.steps / dt
 
@@ -216,6 +235,10 @@ def main():
                        args.rays, "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam"
                        if args.mode == "train" else ("renderer forward only" if args.mode == "forward" else
                                                      "one 640x512 frame per step, forward only, hipGraph-captured 2048-ray chunks" + (" (eager)" if args.no_graph else ""))),
+                       ray_marching=("128 proposals per ray in blocks of %d with early exit at each ray's first sign change (results identical "
+                                     "to evaluating all proposals; the synthetic init-weight scene resolves every ray in the first block)" % eng.march_block
+                                     if eng.march_block else "all 128 proposals per ray"),
+                       without_early_exit=worst,
                        rays_per_gpu=args.rays, samples_per_ray=64, parallelism=f"dp{world}", weights="reference init, torch.manual_seed(0)",
                        algorithmic_gflop_per_ray=dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9,
                                                       train_step=(f_up + 3 * f_core + 2 * 128 * (MAC_D + MAC_S)) / 1e9)),

@@ -11,7 +11,9 @@
 namespace es {
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st);
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
-int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
+int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
+              int ld_out = 0, const int* ray_done = nullptr);
+int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st);
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
@@ -116,6 +118,17 @@ int es_query_sdf(const es_points* pts, const float* packed, const float* weff, f
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
     return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream);
+}
+int es_query_sdf_rays(const es_points* pts, const float* packed, const float* weff, float* sdf_out, int ld_out, const int* ray_done,
+                      int use_deform, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
+    ES_REQUIRE(pts->mode == 1 && pts->n_per_ray >= 1 && ld_out >= pts->n_per_ray, "es_query_sdf_rays takes ray samples (mode 1), ld_out >= n_per_ray");
+    return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream, ld_out, ray_done);
+}
+int es_march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, void* stream) {
+    ES_REQUIRE(sdf && done && n >= 2 && n_valid >= 1 && n_valid <= n, "es_march_progress arguments");
+    return march_progress(sdf, N, n, n_valid, tau, done, (hipStream_t)stream);
 }
 
 

@@ -16,7 +16,8 @@ namespace es {
 // share the batch.
 template <bool DEFORM, bool HALF>
 __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb, const float4* __restrict__ packed,
-                                                        const float* __restrict__ weff, float* __restrict__ sdf_out) {
+                                                        const float* __restrict__ weff, float* __restrict__ sdf_out, int ld_out,
+                                                        const int* __restrict__ ray_done) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
@@ -29,6 +30,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     constexpr int RTC = HALF ? 1 : 2;
     constexpr int PTS = HALF ? 32 : 64;
     const int row0 = blockIdx.x * PTS;
+    if (ray_done != nullptr) {      // block-wise ray marching: a tile whose rays already have their first sign change is skipped
+        const int r_first = row0 / src.n_per_ray, r_last = min(row0 + PTS - 1, src.M - 1) / src.n_per_ray;
+        bool all_done = true;
+        for (int r = r_first; r <= r_last; ++r) all_done = all_done && ray_done[r] != 0;
+        if (all_done) return;       // workgroup-uniform
+    }
 
     if (tid < 64) {
         float x[3], t, d[3];
@@ -120,13 +127,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     }
     smalln_partial<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
     __syncthreads();
-    if (tid < PTS && row0 + tid < src.M) sdf_out[row0 + tid] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+    if (tid < PTS && row0 + tid < src.M) {
+        const int i = row0 + tid;
+        const size_t o = ld_out > 0 ? (size_t)(i / src.n_per_ray) * ld_out + (i % src.n_per_ray) : (size_t)i;   // [ray][ld_out] or flat
+        sdf_out[o] = smalln_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+    }
 }
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
-int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st) {
-    if (src.M > 0 && src.M <= 8192) return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
+int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
+              int ld_out, const int* ray_done) {
+    if (src.M > 0 && src.M <= 8192 && ld_out == 0 && ray_done == nullptr)
+        return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;
@@ -143,11 +156,11 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     const float4* pk = reinterpret_cast<const float4*>(packed);
     ScopedTimer tm(KID_QUERY, src.M, st);
     if (use_deform) {
-        if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
-        else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
+        else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
     } else {
-        if (half) hipLaunchKernelGGL((k_query_sdf<false, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
-        else hipLaunchKernelGGL((k_query_sdf<false, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+        if (half) hipLaunchKernelGGL((k_query_sdf<false, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
+        else hipLaunchKernelGGL((k_query_sdf<false, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
     }
     return hip_last("query_sdf");
 }

@@ -390,6 +390,23 @@ __global__ __launch_bounds__(256) void k_march_find(const float* __restrict__ sd
         d_pred[ray] = -fl * (dh - dl) / (fh - fl) + dl;
     }
 }
+// Block-wise marching: done[ray] = 1 once the outcome of k_march_find is decided by the first n_valid proposals (first point
+// occupied => the ray is masked out; or a sign change among them => later proposals cannot matter, endosurf.py:383-392).
+__global__ __launch_bounds__(256) void k_march_progress(const float* __restrict__ sdf, int N, int n, int n_valid, float tau,
+                                                        int* __restrict__ done) {
+    const int ray = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= N) return;
+    const float* v = sdf + (size_t)ray * n;
+    int found = 0;
+    for (int s = lane; s + 1 < n_valid; s += 64) {
+        const float a0 = -(v[s] - tau), a1 = -(v[s + 1] - tau);
+        if (a0 * a1 < 0.f) found = 1;
+    }
+    if (lane == 0 && !(-(v[0] - tau) < 0.f)) found = 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) found |= __shfl_xor(found, o, 64);
+    if (lane == 0) done[ray] = found;
+}
 // points of a secant iteration: p = o + d_pred * d / d.z   (no epsilon: reference endosurf.py:427)
 __global__ __launch_bounds__(256) void k_secant_points(const float* __restrict__ rays, const float* __restrict__ d_pred, int N,
                                                        float* __restrict__ x, float* __restrict__ t) {
@@ -492,6 +509,11 @@ int march_find(const float* sdf, const float* dprop, int N, int n, float tau, fl
     if (N <= 0) return ST_OK;
     hipLaunchKernelGGL(k_march_find, ray_grid(N), dim3(256), 0, st, sdf, dprop, N, n, tau, state, flags, d_pred);
     return hip_last("march_find");
+}
+int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st) {
+    if (N <= 0) return ST_OK;
+    hipLaunchKernelGGL(k_march_progress, ray_grid(N), dim3(256), 0, st, sdf, N, n, n_valid, tau, done);
+    return hip_last("march_progress");
 }
 int secant_points(const float* rays, const float* d_pred, int N, float* x, float* t, hipStream_t st) {
     if (N <= 0) return ST_OK;

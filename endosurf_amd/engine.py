@@ -31,6 +31,9 @@ class Engine:
         self.n_param = int(self.lib.es_param_floats())
         self.n_weff = int(self.lib.es_weff_floats())
         self.n_packed = int(self.lib.es_packed_floats())
+        import os
+        # ray marching evaluates its proposals in blocks of this many steps with early exit (0: one launch over all proposals)
+        self.march_block = int(os.environ.get("ES_MARCH_BLOCK", "32"))
 
     # ---- buffers ----------------------------------------------------------------------------------
     def empty(self, *shape, dtype=torch.float32):
@@ -181,7 +184,21 @@ class Engine:
         N = rays.shape[0]
         dprop = self.empty(N, n_steps)
         self.ray_setup(rays, None, n_steps, 0.0, 1, dprop)
-        sdf = self.query_sdf(self.points(rays=rays, z=dprop, n_per_ray=n_steps, ldz=n_steps), weff, packed, use_deform)
+        B = self.march_block
+        if B and n_steps % B == 0 and n_steps > B and N * B >= 16384:
+            # proposals in blocks of B steps; a ray is finished at its first sign change (nothing behind it can change the
+            # reference's result), and tiles whose rays are all finished return at once
+            sdf = self.zeros(N, n_steps)                 # skipped proposals read as 0: no sign change
+            done = self.empty(N, dtype=torch.int32)
+            for b in range(n_steps // B):
+                p = self.points(rays=rays, z=dprop, n_per_ray=B, ldz=n_steps)
+                p.z = C.c_void_p(dprop.data_ptr() + 4 * b * B)
+                check(self.lib.es_query_sdf_rays(C.byref(p), ptr(packed), ptr(weff), C.c_void_p(sdf.data_ptr() + 4 * b * B), n_steps,
+                                                 ptr(done) if b else None, int(use_deform), stream_ptr()), "es_query_sdf_rays")
+                if b + 1 < n_steps // B:
+                    check(self.lib.es_march_progress(ptr(sdf), N, n_steps, (b + 1) * B, float(tau), ptr(done), stream_ptr()), "es_march_progress")
+        else:
+            sdf = self.query_sdf(self.points(rays=rays, z=dprop, n_per_ray=n_steps, ldz=n_steps), weff, packed, use_deform)
         state = self.empty(N, 4)
         flags = self.empty(N, dtype=torch.int32)
         d_pred = self.empty(N)

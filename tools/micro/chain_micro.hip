@@ -77,12 +77,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, c
         else gemm_seg<32, 2, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, 2 * wave, lane);
         if (F & 1) __syncthreads();
         if (F & 2) {
-            for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            float* ol = out + (size_t)(l & 7) * gridDim.x * TM * 256;
+            const float* il = out + (size_t)((l + 3) & 7) * gridDim.x * TM * 256;
+            for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
                 const float b = bias[col];
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                if (F & 128) {          // also LOAD an operand per element (backward-style epilogue)
+                    if (F & 64) { const float4 t = *reinterpret_cast<const float4*>(il + grow0 * 256 + ((size_t)(wave * 16 + qi) * 64 + lane) * 4); s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w; }
+                    else g_load_quad(il, grow0, 256, row, col, s);
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b, 0.f);
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b + s[i], 0.f);
                 lds_store_quad(mainT, col, row, v);
-                if (F & 4) g_store_quad(out + (size_t)(l & 7) * gridDim.x * TM * 256, grow0, 256, row, col, v);
+                if (F & 4) {
+                    if (F & 64) *reinterpret_cast<float4*>(ol + grow0 * 256 + ((size_t)(wave * 16 + qi) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    else g_store_quad(ol, grow0, 256, row, col, v);
+                }
             });
         } else {
 #pragma unroll
@@ -126,10 +136,10 @@ int main() {
     run<16>("library gemm_seg PF=2", W, bias, out, blocks, layers);
     run<16 + 7>("library gemm_seg PF=2 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
     run<7>("library gemm_seg PF=4 + barriers + epilogue + HBM", W, bias, out, blocks, layers);
-    run<32 + 7>("PF=2 full + stagger 1", W, bias, out, blocks, layers, 1);
-    run<32 + 7>("PF=2 full + stagger 2", W, bias, out, blocks, layers, 2);
-    run<32 + 7>("PF=2 full + stagger 3", W, bias, out, blocks, layers, 3);
-    run<32 + 7>("PF=2 full + stagger 4", W, bias, out, blocks, layers, 4);
+    run<16 + 7>("row-major stream-out (dword stores)", W, bias, out, blocks, layers);
+    run<16 + 7 + 64>("fragment-order stream-out (dwordx4 stores)", W, bias, out, blocks, layers);
+    run<16 + 7 + 128>("row-major load + store per element", W, bias, out, blocks, layers);
+    run<16 + 7 + 128 + 64>("fragment-order load + store per element", W, bias, out, blocks, layers);
     run<3>("same, 512 blocks (one round)", W, bias, out, 512, layers);
     run<3>("same, 256 blocks (1 workgroup per CU)", W, bias, out, 256, layers);
     return 0;
