@@ -103,14 +103,17 @@ def pmc_traffic(kernel_desc):
     return r["hbm_bytes"] + sum(x["hbm_bytes"] for x in parts.values()), os.path.basename(files[-1])
 
 
-def kernel_timing(eng, step, first_step, n_steps):
+def kernel_timing(eng, step, first_step, n_steps, record=True):
     """A few extra steps of the SAME workload with the library's HIP-event timers on (events recorded on the launch stream
     around every chain / weight-gradient kernel).  Kept out of the headline region so the events do not perturb ``value``."""
-    eng.timing_enable(True)
-    eng.timing_drain()
+    if record:
+        eng.timing_enable(True)
+        eng.timing_drain()
     for i in range(n_steps):
         step(first_step + i)
     torch.cuda.synchronize()
+    if not record:
+        return {}
     rec = eng.timing_drain()
     eng.timing_enable(False)
     groups = {}
@@ -146,8 +149,10 @@ def main():
 
     from endosurf_amd import EndoSurfRenderer, parallel
     from endosurf_amd.trainer import SyntheticScene, Trainer
-    rank, world, local = parallel.init_distributed("nccl" if args.gpus > 1 else None)
+    # one rank per GPU over RCCL ("nccl" on ROCm); ES_DIST_BACKEND=gloo lets the tests drive the N > 1 path on a single GPU
+    rank, world, local = parallel.init_distributed(os.environ.get("ES_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
     assert world == max(1, args.gpus) or args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
@@ -211,7 +216,8 @@ def main():
             dtw = float(t.item())
         eng.march_block = blk
         worst = dict(ms_per_step=dtw / nw * 1e3, value=world * args.rays * nw / dtw, steps=nw)
-    timing = kernel_timing(eng, step, args.warmup + args.steps + 64, 3) if rank == 0 or world == 1 else {}
+    # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 records timers
+    timing = kernel_timing(eng, step, args.warmup + args.steps + 64, 3, record=(rank == 0))
     ms = dt / args.steps * 1e3
     value = world * args.rays * args.steps / dt
 
