@@ -154,7 +154,7 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     const int pts = half ? 32 : 64;
     const dim3 grid((src.M + pts - 1) / pts), block(NTHREADS);
     const float4* pk = reinterpret_cast<const float4*>(packed);
-    ScopedTimer tm(KID_QUERY, src.M, st);
+    ScopedTimer tm(ray_done ? KID_QUERY_EXIT : KID_QUERY, src.M, st);     // launches with early-exit tiles are not counted as work
     if (use_deform) {
         if (half) hipLaunchKernelGGL((k_query_sdf<true, true>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
         else hipLaunchKernelGGL((k_query_sdf<true, false>), grid, block, LEAN_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done);
