@@ -40,7 +40,7 @@ MAC_D, MAC_S, MAC_C = 459520, 544512, 638208
 
 def flops_per_ray_forward(S_c=32, S_i=32, steps=4):
     f_up = 2 * (S_c + S_i * (steps - 1) / steps) * (MAC_D + MAC_S)
-    f_core = 2 * (S_c + S_i) * (4 * MAC_D + 2 * MAC_S + MAC_C)
+    f_core = 2 * (S_c + S_i) * (3 * MAC_D + 2 * MAC_S + MAC_C)      # executed (SURVEY 8d's closed form has 4D: full Jacobian)
     return f_up, f_core
 
 
@@ -78,10 +78,11 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=20):
                 sample=f"{it} full training steps of the CPU oracle at {n_rays} rays x 64 samples (torch-CPU fp32, autograd), {dt:.2f} s/step")
 
 
-# algorithmic MACs per point of each kernel (forward core = 4D + 2S + C, backward chains the same again,
-# weight gradients the same again; the SDF query = D + S)
-KERNEL_MACS = {"k_query_sdf": MAC_D + MAC_S, "k_deform_fwd": 4 * MAC_D, "k_sdf_fwd": 2 * MAC_S, "k_color_fwd": MAC_C,
-               "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_bwd": 4 * MAC_D, "k_wgrad[deform]": 4 * MAC_D,
+# executed MACs per point of each kernel.  The deformation network runs as value + JVP (J d) rows (2D), one VJP sweep
+# (J^T g_c, D) and, in the backward, one tangent sweep (J gbar_o, D): 3D per pass instead of SURVEY 8d's 4D (value + three
+# basis tangents); SDF 2S (value + reverse / tangent + reverse), colour C; weight gradients the same again; the SDF query = D + S
+KERNEL_MACS = {"k_query_sdf": MAC_D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S, "k_color_fwd": MAC_C,
+               "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D, "k_wgrad[deform]": 3 * MAC_D,
                "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}
 
 

@@ -80,7 +80,7 @@ PROTOTYPES = {
 }
 
 PF_DEFORM, PF_COLOR, PF_SAVE = 1, 2, 4
-WS_XC, WS_J, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
+WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 
 _lib = None
 

@@ -80,7 +80,7 @@ enum Seg : int {
     // deform forward
     DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7,
     // deform reverse (input adjoint = output adjoint x W)
-    DR1, DR2, DR3, DR4, DR5, DR6, DR7,
+    DR0, DR1, DR2, DR3, DR4, DR5, DR6, DR7,
     // sdf forward
     SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7, SF8F,
     // sdf reverse
@@ -102,6 +102,7 @@ constexpr SegDesc SEGS[SEG_COUNT] = {
     {0, 5, 0, 0, 0, 256, 256, 0},  // DF5
     {0, 6, 0, 0, 0, 256, 256, 0},  // DF6
     {0, 7, 0, 0, 0, 256, 256, 0},  // DF7
+    {0, 0, 1, 0, 0, 256, 52, 0},   // DR0 (adjoint of the 52-wide encoding input: the VJP sweep J^T g)
     {0, 1, 1, 0, 0, 256, 256, 0},  // DR1
     {0, 2, 1, 0, 0, 256, 256, 0},  // DR2
     {0, 3, 1, 0, 0, 204, 256, 0},  // DR3 (contract over the 204 outputs)

@@ -97,10 +97,8 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
         float v0 = dray[0], v1 = dray[1], v2 = dray[2];
         if (deform) {
-            const float* J = wsb(a, WS_J) + gp * 9;
-            v0 = J[0] * dray[0] + J[1] * dray[1] + J[2] * dray[2];
-            v1 = J[3] * dray[0] + J[4] * dray[1] + J[5] * dray[2];
-            v2 = J[6] * dray[0] + J[7] * dray[1] + J[8] * dray[2];
+            const float* v = wsb(a, WS_V) + gp * 3;
+            v0 = v[0]; v1 = v[1]; v2 = v[2];
         }
         const float inv = 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
         pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
@@ -198,26 +196,20 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         const size_t gp = grow0 + tid;
         float* xb = wsb(a, WS_XCBAR_C) + gp * 3;
         float* gb = wsb(a, WS_GCBAR_C) + gp * 3;
-        float* Jb = wsb(a, WS_JBAR_C) + gp * 9;
+        float* Vb = wsb(a, WS_VBAR_C) + gp * 3;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { xb[j] = tx[j * 64 + tid]; gb[j] = SB[gp * 128 + 63 + j]; }
-        if (deform) {   // d_c = v/(|v| + eps), v = J d  ->  vbar, Jbar = vbar d^T
-            const float* J = wsb(a, WS_J) + gp * 9;
-            float v[3], db[3] = {td[tid], td[64 + tid], td[128 + tid]};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = J[3 * i] * dray[0] + J[3 * i + 1] * dray[1] + J[3 * i + 2] * dray[2];
+        if (deform) {   // d_c = v/(|v| + eps), v = J d  ->  vbar (seeds the J d row of the deformation backward)
+            const float* vv = wsb(a, WS_V) + gp * 3;
+            const float v[3] = {vv[0], vv[1], vv[2]}, db[3] = {td[tid], td[64 + tid], td[128 + tid]};
             const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
             const float den = n + 1e-10f;
             const float dot = v[0] * db[0] + v[1] * db[1] + v[2] * db[2];
             const float k2 = n > 0.f ? dot / (n * den * den) : 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float vb = db[i] / den - v[i] * k2;
-                Jb[3 * i] = vb * dray[0]; Jb[3 * i + 1] = vb * dray[1]; Jb[3 * i + 2] = vb * dray[2];
-            }
+            for (int i = 0; i < 3; ++i) Vb[i] = db[i] / den - v[i] * k2;
         } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Jb[i] = 0.f;
+            Vb[0] = Vb[1] = Vb[2] = 0.f;
         }
     }
 }
@@ -249,22 +241,10 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
         sb[tid] = valid ? a.d_sdf[row0 + tid] : 0.f;
         const float* xc = wsb(a, WS_XC) + gp * 3;
         px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
-        const float* gc = wsb(a, WS_GC) + gp * 3;
-        float Jm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-        if (deform) {
-            const float* J = wsb(a, WS_J) + gp * 9;
+        // gbar_c = J gbar_o (+ the colour network's): J gbar_o comes from the deformation tangent sweep (deform_tan_tile)
+        const float* ju = deform ? wsb(a, WS_JU) + gp * 3 : go;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Jm[i] = J[i];
-        }
-        float* Jb = wsb(a, WS_JBAR) + gp * 9;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float g = Jm[3 * i] * go[0] + Jm[3 * i + 1] * go[1] + Jm[3 * i + 2] * go[2];       // g_o = J^T g_c  ->  gbar_c = J gbar_o
-            if (color) g += wsb(a, WS_GCBAR_C)[gp * 3 + i];
-            gb[i * 64 + tid] = g;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) Jb[3 * i + k] = (color ? wsb(a, WS_JBAR_C)[gp * 9 + 3 * i + k] : 0.f) + gc[i] * go[k];
-        }
+        for (int i = 0; i < 3; ++i) gb[i * 64 + tid] = ju[i] + (color ? wsb(a, WS_GCBAR_C)[gp * 3 + i] : 0.f);
     }
     __syncthreads();
     {   // tau_0 = (d enc6 / d x_c) gbar_c
@@ -416,8 +396,101 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// LDS: activation tile + 768 B only => two workgroups per CU (2 waves per SIMD): one workgroup's epilogue / barrier
-// phases overlap the other's MFMA stream.
+// Deformation network, forward tangent sweep along gbar_o (the adjoint of g_o = J^T g_c with respect to g_c is J gbar_o):
+//   tau_0 = E(x) gbar_o,  tau_{l+1} = M_l (W_l tau_l),  J gbar_o = gbar_o + W_8 tau_8.
+// Tile = 64 points, one row per point.  tau_0..tau_8 are kept: (tau_l, r_l) with the r_l of the VJP sweep is the weight
+// gradient of the g_o path.  Runs before the SDF backward, which consumes J gbar_o.
+__device__ __forceinline__ void deform_tan_tile(const BwdArgs& a, const int tile) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;          // 56 rows: tau_0 (52 valid)
+    float* scr = aux + AUX56_FLOATS;
+    float* ub = scr;                         // [3][64] gbar_o
+    float* px = mainT;                       // [3][64] x, only until the first epilogue overwrites the tile
+    float* red = aux;                        // [4][3][64]: tau_0 is dead after layer 3's epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = tile * TM;
+    const size_t grow0 = (size_t)row0;
+    const size_t Mp = (size_t)a.L.Mp;
+    const float* U = wsb(a, WS_D_U);         // value row of point r = row 2r  ->  leading dimension 512
+    float* T = wsb(a, WS_D_T);
+
+    if (tid < 64) {
+        const bool valid = row0 + tid < a.src.M;
+        float x[3], t, d[3];
+        load_point(a.src, row0 + tid, x, t, d);
+        px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ub[i * 64 + tid] = valid ? a.d_go[3 * (size_t)(row0 + tid) + i] : 0.f;
+    }
+    zero_rows(aux, 0, 56, tid);
+    __syncthreads();
+    {
+        const int row = tid & 63, part = tid >> 6;
+        for (int item = part; item < 18; item += 4) {
+            const int c = item % 3, i = item / 3;
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(px[c * 64 + row] * f, &s, &co);
+            const float g = ub[c * 64 + row];
+            aux[swz(enc_index(3, i, 0, c), row)] = f * co * g;
+            aux[swz(enc_index(3, i, 1, c), row)] = -f * s * g;
+        }
+        if (part == 3) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) aux[swz(c, row)] = ub[c * 64 + row];
+        }
+    }
+    __syncthreads();
+    {
+        float* T0 = wsb(a, WS_D_T0);
+        const int r = tid >> 2, c4 = tid & 3;
+        for (int k = c4; k < 56; k += 4) T0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+    }
+    auto epi = [&](f32x16(&acc)[2][2], int l) {
+        const float* Ul = U + (size_t)l * 2 * Mp * 256;
+        float* Tl = T + (size_t)l * Mp * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            if (l == 3 && col >= 204) {
+                lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
+            } else {
+                float m[4];
+                g_load_quad(Ul, grow0, 512, row, col, m);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+            }
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad(Tl, grow0, 256, row, col, v);
+        });
+    };
+    {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
+        epi(acc, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
+        __syncthreads();
+        epi(acc, l);
+        __syncthreads();
+    }
+    smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
+    __syncthreads();
+    if (tid < 192) {
+        const int i = tid >> 6, row = tid & 63;
+        wsb(a, WS_JU)[(grow0 + row) * 3 + i] = smalln_reduce<3>(red, i, row) + ub[i * 64 + row];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Deformation network, reverse sweep of the value row (seed xbar_c) and of the J d row (seed vbar from the colour network).
+// Tile = 32 points = 64 rows (row 2p = value, 2p + 1 = tangent).  LDS: activation tile + 768 B => two workgroups per CU.
 constexpr int DBWD_LDS_BYTES = (MAIN_FLOATS + 192) * 4;
 __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -425,17 +498,19 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
     float* a8 = lds + MAIN_FLOATS;   // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = tile * 16;
-    const size_t grow0 = (size_t)pt0 * 4;
-    const size_t rows4 = (size_t)a.L.Mp * 4;
+    const int pt0 = tile * 32;
+    const size_t grow0 = (size_t)pt0 * 2;
+    const size_t rows2 = (size_t)a.L.Mp * 2;
+    const bool color = a.flags & PF_COLOR;
 
     if (tid < 64) {
-        const int p = tid >> 2, c = tid & 3;
+        const int p = tid >> 1, c = tid & 1;
         const size_t gp = (size_t)(pt0 + p);
+        const bool has_v = color && pt0 + p < a.M_color;
         float* A8 = wsb(a, WS_D_A8) + (grow0 + tid) * 4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float v = c == 0 ? wsb(a, WS_XCBAR)[gp * 3 + i] : wsb(a, WS_JBAR)[gp * 9 + 3 * i + (c - 1)];
+            const float v = c == 0 ? wsb(a, WS_XCBAR)[gp * 3 + i] : (has_v ? wsb(a, WS_VBAR_C)[gp * 3 + i] : 0.f);
             a8[i * 64 + tid] = v; A8[i] = v;
         }
         A8[3] = 0.f;
@@ -445,33 +520,35 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
     float* DA = wsb(a, WS_D_A);
     {   // abar_7 = mask_7 * (W8^T abar_8)
         const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
+        const float* U7 = U + (size_t)7 * rows2 * 256;
         for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
             const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
-            const bool m = U[(size_t)7 * rows4 * 256 + (grow0 + row) * 256 + col] > 0.f;   // value row of this point
+            const bool m0 = U7[(grow0 + row) * 256 + col] > 0.f, m2 = U7[(grow0 + row + 2) * 256 + col] > 0.f;   // value rows
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = m ? a8[row + i] * w0 + a8[64 + row + i] * w1 + a8[128 + row + i] * w2 : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = (i < 2 ? m0 : m2) ? a8[row + i] * w0 + a8[64 + row + i] * w1 + a8[128 + row + i] * w2 : 0.f;
             lds_store_quad(mainT, col, row, v);
-            g_store_quad(DA + (size_t)7 * rows4 * 256, grow0, 256, row, col, v);
+            g_store_quad(DA + (size_t)7 * rows2 * 256, grow0, 256, row, col, v);
         });
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-        const float* Ul = U + (size_t)(l - 1) * rows4 * 256;
-        float upre[16];                                                               // value-row activations, in flight during the GEMM
+        const float* Ul = U + (size_t)(l - 1) * rows2 * 256;
+        float upre[16], upre2[16];                                                    // value-row activations, in flight during the GEMM
         prefetch_quad_heads<2, 2>(upre, Ul, grow0, 256, 0, 2 * wave, lane);
+        prefetch_quad_heads<2, 2>(upre2, Ul, grow0 + 2, 256, 0, 2 * wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
-        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR1 + (l - 1)], 0, 2 * wave, lane);
+        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
         __syncthreads();
-        float* Al = DA + (size_t)(l - 1) * rows4 * 256;
+        float* Al = DA + (size_t)(l - 1) * rows2 * 256;
         for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             // layer 3 has 204 outputs: the skip's encoding part (cols >= 204) carries no parameter gradient
-            const bool m = (l == 4 && col >= 204) ? false : upre[qi] > 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = m ? v[i] : 0.f;
+            const bool dead = l == 4 && col >= 204;
+            const bool m0 = !dead && upre[qi] > 0.f, m2 = !dead && upre2[qi] > 0.f;
+            v[0] = m0 ? v[0] : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? v[2] : 0.f; v[3] = m2 ? v[3] : 0.f;
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Al, grow0, 256, row, col, v);
         });
@@ -482,12 +559,13 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
 // -------------------------------------------------------------------------------------------------------------
 // Two-segment launches as in point_fwd.hip: the tail's two dependent stages ride in the halves of the main deformation launch
 //   colour_bwd(main) | sdf_bwd(main) | sdf_bwd(tail) + deform_bwd(main, 1st half) | deform_bwd(tail) + deform_bwd(main, 2nd half)
-enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM };
+enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM, BB_TAN };
 template <int B>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a, int tile) {
     if constexpr (B == BB_COLOR) color_bwd_tile(a, tile);
     else if constexpr (B == BB_SDF) sdf_bwd_tile(a, tile);
     else if constexpr (B == BB_DEFORM) deform_bwd_tile(a, tile);
+    else if constexpr (B == BB_TAN) deform_tan_tile(a, tile);
 }
 template <int B0, int B1>
 __global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, int t0, int t1) {
@@ -496,7 +574,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, in
     }
     bwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
 }
-constexpr int bwd_lds(int b) { return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : 0)); }
+constexpr int bwd_lds(int b) {
+    return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : (b == BB_TAN ? LEAN_LDS_BYTES : 0)));
+}
 template <int B0, int B1>
 static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
     constexpr int lds = bwd_lds(B0) > bwd_lds(B1) ? bwd_lds(B0) : bwd_lds(B1);
@@ -519,18 +599,10 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
-    if (deform && aux_tail(flags, a.M_color, src.M)) {
-        const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
-        { ScopedTimer tm(KID_COLOR_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
-        { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
-        { ScopedTimer tm(KID_DEFORM_BWD, src.M, st);      // all deformation tiles (+ the tail's SDF tiles, not counted as work)
-          if (int e = launch_bwd<BB_SDF, BB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, h, 0, st)) return e;
-          if (int e = launch_bwd<BB_DEFORM, BB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, nd - h, h, st)) return e; }
-        return hip_last("point_backward_chains");
-    }
+    if (deform) { ScopedTimer tm(KID_DEFORM_TAN, src.M, st); if (int e = launch_bwd<BB_NONE, BB_TAN>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
-    if (deform) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, Mp / 16, 0, st)) return e; }
+    if (deform) { ScopedTimer tm(KID_DEFORM_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, Mp / 32, 0, st)) return e; }
     return hip_last("point_backward_chains");
 }
 

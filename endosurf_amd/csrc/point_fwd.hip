@@ -29,57 +29,61 @@ struct FwdArgs {
 __device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws + a.L.off[buf]; }
 
 // -------------------------------------------------------------------------------------------------------------
-// deformation network, value + 3 tangents.  Tile = 16 points = 64 rows (row 4p + c).
-// Two workgroups per CU (lean LDS carve, <= 256 registers): one workgroup's epilogue/barrier phases hide under the other's MFMAs.
+// deformation network, value + forward-mode tangent along the ray direction d:  x_c = x + MLP(x, t) and v = J d.
+// Tile = 32 points = 64 rows (row 2p = value, row 2p + 1 = tangent).  The layer outputs u_1..u_8 are always streamed out:
+// their value rows are the ReLU masks of the VJP sweep below (inference writes only those rows).
 __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
     float* scr = aux + AUX56_FLOATS;
-    float* px = scr;         // [3][16]
-    float* pt = scr + 48;    // [16]
+    float* px = scr;         // [3][32]
+    float* pd = scr + 96;    // [3][32] ray direction
+    float* pt = scr + 192;   // [32]
     float* red = aux;        // [4][3][64]: the encoding rows are dead after layer 3's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = tile * 16;
-    const size_t grow0 = (size_t)pt0 * 4;
+    const int pt0 = tile * 32;
+    const size_t grow0 = (size_t)pt0 * 2;
     const bool save = a.flags & PF_SAVE;
-    const size_t rows4 = (size_t)a.L.Mp * 4;
+    const size_t rows2 = (size_t)a.L.Mp * 2;
 
-    if (tid < 16) {
+    if (tid < 32) {
         float x[3], t, d[3];
         load_point(a.src, pt0 + tid, x, t, d);
-        px[tid] = x[0]; px[16 + tid] = x[1]; px[32 + tid] = x[2]; pt[tid] = t;
+        px[tid] = x[0]; px[32 + tid] = x[1]; px[64 + tid] = x[2]; pt[tid] = t;
+        pd[tid] = d[0]; pd[32 + tid] = d[1]; pd[64 + tid] = d[2];
     }
     zero_rows(aux, 0, 56, tid);
     __syncthreads();
-    {   // encoding rows: value row 4p, tangent rows 4p+1+c (d/dx_c); time part has no tangent
-        const int p = tid & 15;
-        for (int item = tid >> 4; item < 25; item += 16) {
+    {   // encoding rows: value row 2p, tangent row 2p+1 = (d enc / d x) d; the time part has no tangent
+        const int p = tid & 31;
+        for (int item = tid >> 5; item < 25; item += 8) {
             if (item < 18) {
                 const int c = item % 3, i = item / 3;
                 const float f = (float)(1 << i);
                 float s, co;
-                sincosf(px[c * 16 + p] * f, &s, &co);
-                aux[swz(enc_index(3, i, 0, c), 4 * p)] = s;
-                aux[swz(enc_index(3, i, 1, c), 4 * p)] = co;
-                aux[swz(enc_index(3, i, 0, c), 4 * p + 1 + c)] = f * co;
-                aux[swz(enc_index(3, i, 1, c), 4 * p + 1 + c)] = -f * s;
+                sincosf(px[c * 32 + p] * f, &s, &co);
+                const float dc = pd[c * 32 + p];
+                aux[swz(enc_index(3, i, 0, c), 2 * p)] = s;
+                aux[swz(enc_index(3, i, 1, c), 2 * p)] = co;
+                aux[swz(enc_index(3, i, 0, c), 2 * p + 1)] = f * co * dc;
+                aux[swz(enc_index(3, i, 1, c), 2 * p + 1)] = -f * s * dc;
             } else if (item < 24) {
                 const int i = item - 18;
                 float s, co;
                 sincosf(pt[p] * (float)(1 << i), &s, &co);
-                aux[swz(39 + enc_index(1, i, 0, 0), 4 * p)] = s;
-                aux[swz(39 + enc_index(1, i, 1, 0), 4 * p)] = co;
+                aux[swz(39 + enc_index(1, i, 0, 0), 2 * p)] = s;
+                aux[swz(39 + enc_index(1, i, 1, 0), 2 * p)] = co;
             } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { aux[swz(c, 4 * p)] = px[c * 16 + p]; aux[swz(c, 4 * p + 1 + c)] = 1.f; }
-                aux[swz(39, 4 * p)] = pt[p];
+                for (int c = 0; c < 3; ++c) { aux[swz(c, 2 * p)] = px[c * 32 + p]; aux[swz(c, 2 * p + 1)] = pd[c * 32 + p]; }
+                aux[swz(39, 2 * p)] = pt[p];
             }
         }
     }
     __syncthreads();
-    if (save) {   // u_0 rows for the weight-gradient GEMM: [4Mp][64], 56 columns written
+    if (save) {   // u_0 rows for the weight-gradient GEMM: [2Mp][64], 56 columns written
         float* U0 = wsb(a, WS_D_U0);
         const int r = tid >> 2, c4 = tid & 3;
         for (int k = c4; k < 56; k += 4) U0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
@@ -88,17 +92,19 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     float* U = wsb(a, WS_D_U);
     auto epi = [&](f32x16(&acc)[2][2], int l) {
         const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l];
-        float* Ul = U + (size_t)l * rows4 * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        float* Ul = U + (size_t)l * rows2 * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {       // rows: value, tangent, value, tangent
             if (l == 3 && col >= 204) {
                 lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
             } else {
-                const float av = v[0] + bias[col];
-                const bool m = av > 0.f;                          // ReLU mask of the value row gates its tangents
-                v[0] = m ? av : 0.f; v[1] = m ? v[1] : 0.f; v[2] = m ? v[2] : 0.f; v[3] = m ? v[3] : 0.f;
+                const float b = bias[col];
+                const float a0 = v[0] + b, a2 = v[2] + b;
+                const bool m0 = a0 > 0.f, m2 = a2 > 0.f;         // the ReLU mask of a value row gates its tangent
+                v[0] = m0 ? a0 : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? a2 : 0.f; v[3] = m2 ? v[3] : 0.f;
             }
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(Ul, grow0, 256, row, col, v);
+            else { Ul[(grow0 + row) * 256 + col] = v[0]; Ul[(grow0 + row + 2) * 256 + col] = v[2]; }
         });
     };
     {
@@ -120,11 +126,99 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
     __syncthreads();
     if (tid < 192) {
-        const int i = tid >> 6, row = tid & 63, p = row >> 2, c = row & 3;
+        const int i = tid >> 6, row = tid & 63, p = row >> 1, c = row & 1;
         const float val = smalln_reduce<3>(red, i, row);
         const size_t gp = (size_t)(pt0 + p);
-        if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 16 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
-        else wsb(a, WS_J)[gp * 9 + i * 3 + (c - 1)] = val + (i == c - 1 ? 1.f : 0.f);
+        if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 32 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
+        else wsb(a, WS_V)[gp * 3 + i] = val + pd[i * 32 + p];          // J d = d + (d Delta x / d x) d
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// deformation network, reverse (VJP) sweep for the covector g_c:  g_o = J^T g_c = g_c + E(x)^T W_0^T M_0 W_1^T ... M_7 W_8^T g_c
+// (get_sdf_grad_from_observed_space, endosurf.py:581-601, is exactly this product).  Tile = 64 points, one row per point;
+// masks M_l from the value rows of u_{l+1}.  With PF_SAVE the adjoints r_0..r_7 are kept: paired with the tangent sweep of
+// the backward pass they give this path's weight gradient.
+__device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    float* aux = lds + MAIN_FLOATS;          // adjoint of the 52 encoding inputs (skip part + layer 0), rows 52..55 zero
+    float* scr = aux + AUX56_FLOATS;
+    float* g8 = scr;                         // [3][64] g_c
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = tile * TM;
+    const size_t grow0 = (size_t)row0;
+    const bool save = a.flags & PF_SAVE;
+    const size_t Mp = (size_t)a.L.Mp;
+    const float* U = wsb(a, WS_D_U);         // [8][2Mp][256]: value row of point r = row 2r  ->  leading dimension 512
+    float* R = wsb(a, WS_D_R);
+
+    if (tid < 64) {
+        const float* gc = wsb(a, WS_GC) + (grow0 + tid) * 3;
+        g8[tid] = gc[0]; g8[64 + tid] = gc[1]; g8[128 + tid] = gc[2];
+    }
+    zero_rows(aux, 0, 56, tid);
+    __syncthreads();
+    {   // r_7 = mask_7 * (W8^T g_c)
+        const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
+        const float* U7 = U + (size_t)7 * 2 * Mp * 256;
+        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+            const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
+            float m[4], v[4];
+            g_load_quad(U7, grow0, 512, row, col, m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? g8[row + i] * w0 + g8[64 + row + i] * w1 + g8[128 + row + i] * w2 : 0.f;
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(R + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+        });
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
+        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
+        __syncthreads();
+        const float* Ul = U + (size_t)(l - 1) * 2 * Mp * 256;
+        float* Rl = R + (size_t)(l - 1) * Mp * 256;
+        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+            if (l == 4 && col >= 204) {
+                lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
+            } else {
+                float m[4];
+                g_load_quad(Ul, grow0, 512, row, col, m);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+            }
+            lds_store_quad(mainT, col, row, v);
+            if (save) g_store_quad(Rl, grow0, 256, row, col, v);
+        });
+        __syncthreads();
+    }
+    {   // adjoint of the encoding input: += W_0^T r_0
+        f32x16 accA[1][1];
+        acc_zero(accA);
+        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[DR0], wave >> 1, wave & 1, lane);
+        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 52) lds_add_quad(aux, col, row, v); });
+    }
+    __syncthreads();
+    if (tid < 192) {   // g_o[j] = g_c[j] + sum_k adj[k] * d enc_k / d x_j   (position part of the encoding, observed-space x)
+        const int j = tid >> 6, row = tid & 63;
+        float x[3], t, d[3];
+        load_point(a.src, row0 + row, x, t, d);
+        float g = g8[j * 64 + row] + aux[swz(j, row)];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(x[j] * f, &s, &co);
+            g += f * (aux[swz(enc_index(3, i, 0, j), row)] * co - aux[swz(enc_index(3, i, 1, j), row)] * s);
+        }
+        wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
     }
 }
 
@@ -285,13 +379,8 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         const float g0 = gcv[tid], g1 = gcv[64 + tid], g2 = gcv[128 + tid];
         float* gc = wsb(a, WS_GC) + gp * 3;
         gc[0] = g0; gc[1] = g1; gc[2] = g2;
-        float* go = wsb(a, WS_GO) + gp * 3;
-        if (deform) {
-            const float* J = wsb(a, WS_J) + gp * 9;      // g_o[k] = sum_i J[i][k] g_c[i]
-            go[0] = J[0] * g0 + J[3] * g1 + J[6] * g2;
-            go[1] = J[1] * g0 + J[4] * g1 + J[7] * g2;
-            go[2] = J[2] * g0 + J[5] * g1 + J[8] * g2;
-        } else {
+        if (!deform) {      // with a deformation network g_o = J^T g_c is the VJP sweep (deform_vjp_tile)
+            float* go = wsb(a, WS_GO) + gp * 3;
             go[0] = g0; go[1] = g1; go[2] = g2;
         }
     }
@@ -328,10 +417,8 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
         pg[tid] = gc[0]; pg[64 + tid] = gc[1]; pg[128 + tid] = gc[2];
         float v0 = d[0], v1 = d[1], v2 = d[2];
         if (deform) {
-            const float* J = wsb(a, WS_J) + gp * 9;      // d_c = J d / (|J d| + 1e-10)   endosurf.py:684-685
-            v0 = J[0] * d[0] + J[1] * d[1] + J[2] * d[2];
-            v1 = J[3] * d[0] + J[4] * d[1] + J[5] * d[2];
-            v2 = J[6] * d[0] + J[7] * d[1] + J[8] * d[2];
+            const float* v = wsb(a, WS_V) + gp * 3;      // d_c = J d / (|J d| + 1e-10)   endosurf.py:684-685
+            v0 = v[0]; v1 = v[1]; v2 = v[2];
         }
         const float inv = 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
         pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
@@ -409,12 +496,13 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
 // kernels (1024 + 48 tiles), which costs a full tile time.  Every main launch of this workload is a whole number of rounds,
 // so extra tiles always cost something -- least inside a launch of MANY short rounds: the tail's two dependent stages
 // (deform, then SDF) are therefore mixed into the two halves of the 8-round deformation launch of the main tiles.
-enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR };
+enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP };
 template <int B>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
     if constexpr (B == FB_DEFORM) deform_fwd_tile(a, tile);
     else if constexpr (B == FB_SDF) sdf_fwd_tile(a, tile);
     else if constexpr (B == FB_COLOR) color_fwd_tile(a, tile);
+    else if constexpr (B == FB_VJP) deform_vjp_tile(a, tile);
 }
 template <int B0, int B1>
 __global__ __launch_bounds__(NTHREADS, 2) void k_point_fwd(FwdArgs a, int n0, int t0, int t1) {
@@ -446,20 +534,10 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
-    if (deform && aux_tail(flags, a.M_color, src.M)) {
-        // main tiles [0, Mc), colour-less tail [Mc, Mp):
-        //   deform(tail) + deform(main, 1st half) | sdf(tail) + deform(main, 2nd half) | sdf(main) | colour(main)
-        const int Mc = a.M_color, nd = Mc / 16, h = (nd / 2 + 511) / 512 * 512 < nd ? (nd / 2 + 511) / 512 * 512 : nd / 2;
-        { ScopedTimer tm(KID_DEFORM_FWD, src.M, st);      // all deformation tiles (+ the tail's SDF tiles, not counted as work)
-          if (int e = launch_fwd<FB_DEFORM, FB_DEFORM>(a, (Mp - Mc) / 16, Mc / 16, h, 0, st)) return e;
-          if (int e = launch_fwd<FB_SDF, FB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, nd - h, h, st)) return e; }
-        { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
-        { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
-        return hip_last("point_forward");
-    }
-    if (deform) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mp / 16, 0, st)) return e; }
+    if (deform) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mp / 32, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
+    if (deform) { ScopedTimer tm(KID_DEFORM_VJP, src.M, st); if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, Mp / TM, 0, st)) return e; }
     return hip_last("point_forward");
 }
 

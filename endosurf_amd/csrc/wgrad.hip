@@ -258,15 +258,22 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0};
     };
     if (flags & PF_DEFORM) {
-        const int R = 4 * Mp;
+        // value + J d rows: (u_l, abar_l) over 2 rows per point (bias gradient from the value rows only); VJP / tangent pair:
+        // (tau_l, r_l) over 1 row per point (g_o = J^T g_c is linear in every W_l: dW_l += r_l tau_l^T)
+        const int R = 2 * Mp;
         const size_t r256 = (size_t)R * 256;
         n = 0;
-        add(B(WS_D_U0), 64, B(WS_D_A), 256, R, 52, 256, dW(NET_D, 0), 52, dB(NET_D, 0), 4);
-        for (int l = 1; l <= 7; ++l)
+        add(B(WS_D_U0), 64, B(WS_D_A), 256, R, 52, 256, dW(NET_D, 0), 52, dB(NET_D, 0), 2);
+        add(B(WS_D_T0), 64, B(WS_D_R), 256, Mp, 52, 256, dW(NET_D, 0), 52, nullptr, 1);
+        for (int l = 1; l <= 7; ++l) {
             add(B(WS_D_U) + (size_t)(l - 1) * r256, 256, B(WS_D_A) + (size_t)l * r256, 256, R, 256, LAYER_N[NET_D][l], dW(NET_D, l), 256,
-                dB(NET_D, l), 4);
+                dB(NET_D, l), 2);
+            add(B(WS_D_T) + (size_t)(l - 1) * t256, 256, B(WS_D_R) + (size_t)l * t256, 256, Mp, 256, LAYER_N[NET_D][l], dW(NET_D, l), 256,
+                nullptr, 1);
+        }
         if (int e = launch_group(g, n, KID_WGRAD_D, M, st)) return e;
-        launch_small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 4, st);
+        launch_small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2, st);
+        launch_small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1, st);
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l)
         n = 0;

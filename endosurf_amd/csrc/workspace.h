@@ -2,7 +2,8 @@
 //
 // All per-point tensors are row-major [Mp][ld] with Mp = M rounded up to a multiple of 64 so that tiles never
 // need row guards; rows >= M carry finite junk in forward buffers and exact zeros in every adjoint buffer.
-// Deformation-network buffers have 4 rows per point: row 4p = value, rows 4p+1..3 = d/dx_0..2 tangents.
+// Deformation-network value/JVP buffers have 2 rows per point: row 2p = value, row 2p+1 = tangent along the ray direction d
+// (J d); the VJP sweep (J^T g_c) and the backward's tangent sweep (J gbar_o) have 1 row per point.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -16,11 +17,12 @@ constexpr int PF_SAVE = 4;     // keep activations for the backward pass (traini
 
 enum WsBuf : int {
     // forward outputs
-    WS_XC, WS_J, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB,
+    WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB,      // WS_V = J d (3 per point)
     // forward saves
     WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them)
-    WS_D_U0,       // [4Mp][64]     deform encoding rows (52 valid)
-    WS_D_U,        // [8][4Mp][256] u_1..u_8
+    WS_D_U0,       // [2Mp][64]     deform encoding rows (52 valid)
+    WS_D_U,        // [8][2Mp][256] u_1..u_8 (always written: the value rows are the ReLU masks of the VJP / tangent sweeps)
+    WS_D_R,        // [8][Mp][256]  VJP sweep: adjoints r_0..r_7 of the pre-activations for the covector g_c
     WS_S_S0,       // [Mp][64]      enc6(x_c) (39 valid)
     WS_S_RHO,      // [8][Mp][256]  d sdf / d z_0..7
     WS_S_ADJEPS,   // [Mp][64]      d sdf / d enc6(x_c)
@@ -30,13 +32,16 @@ enum WsBuf : int {
     WS_C_Y,        // [8][Mp][256]  adjoints of colour pre-activations y_0..7
     WS_C_Y8,       // [Mp][4]
     WS_FEATBAR,    // [Mp][256]
-    WS_XCBAR_C, WS_GCBAR_C, WS_JBAR_C,
+    WS_XCBAR_C, WS_GCBAR_C, WS_VBAR_C,     // adjoints of x_c, g_c and v = J d from the colour network
     WS_S_TAU0,     // [Mp][64]
     WS_S_TAU,      // [8][Mp][256]  tau_1..tau_8
     WS_S_ZB,       // [8][Mp][256]  second-order terms, overwritten in place by the adjoints of z_0..7
-    WS_XCBAR, WS_JBAR,
-    WS_D_A,        // [8][4Mp][256] adjoints of deform pre-activations a_0..7
-    WS_D_A8,       // [4Mp][4]
+    WS_XCBAR,
+    WS_JU,         // [Mp][3]       J gbar_o (adjoint of g_c through g_o = J^T g_c)
+    WS_D_T0,       // [Mp][64]      tangent sweep along gbar_o: encoding tangent (52 valid)
+    WS_D_T,        // [8][Mp][256]  tau_1..tau_8
+    WS_D_A,        // [8][2Mp][256] adjoints of deform pre-activations a_0..7 (value row, J d row)
+    WS_D_A8,       // [2Mp][4]
     WS_C_SBAR,     // [Mp][128]     adjoint of the colour input's small part (93 valid)
     WS_COUNT
 };
@@ -54,18 +59,22 @@ inline WsLayout ws_layout(int M, int flags) {
     L.Mp = (int)Mp;
     const bool def = flags & PF_DEFORM, col = flags & PF_COLOR, save = flags & PF_SAVE;
     size_t sz[WS_COUNT] = {0};
-    sz[WS_XC] = Mp * 3; sz[WS_J] = Mp * 9; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
+    sz[WS_XC] = Mp * 3; sz[WS_V] = Mp * 3; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
+    sz[WS_D_U] = def ? 8 * 2 * Mp * 256 : 0;
     sz[WS_FEAT] = col ? Mp * 256 : 0; sz[WS_RGB] = col ? Mp * 3 : 0;
     sz[WS_C_IN] = col ? Mp * 128 : 0;      // always: the colour kernel re-stages it at the skip layer
     sz[WS_S_ACT] = 8 * Mp * 256;
     if (save) {
-        if (def) { sz[WS_D_U0] = 4 * Mp * 64; sz[WS_D_U] = 8 * 4 * Mp * 256; sz[WS_D_A] = 8 * 4 * Mp * 256; sz[WS_D_A8] = 4 * Mp * 4; }
+        if (def) {
+            sz[WS_D_U0] = 2 * Mp * 64; sz[WS_D_A] = 8 * 2 * Mp * 256; sz[WS_D_A8] = 2 * Mp * 4;
+            sz[WS_D_R] = 8 * Mp * 256; sz[WS_JU] = Mp * 3; sz[WS_D_T0] = Mp * 64; sz[WS_D_T] = 8 * Mp * 256;
+        }
         sz[WS_S_S0] = Mp * 64; sz[WS_S_RHO] = 8 * Mp * 256; sz[WS_S_ADJEPS] = Mp * 64;
         sz[WS_S_TAU0] = Mp * 64; sz[WS_S_TAU] = 8 * Mp * 256; sz[WS_S_ZB] = 8 * Mp * 256;
-        sz[WS_XCBAR] = Mp * 3; sz[WS_JBAR] = Mp * 9;
+        sz[WS_XCBAR] = Mp * 3;
         if (col) {
             sz[WS_C_SBAR] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
-            sz[WS_FEATBAR] = Mp * 256; sz[WS_XCBAR_C] = Mp * 3; sz[WS_GCBAR_C] = Mp * 3; sz[WS_JBAR_C] = Mp * 9;
+            sz[WS_FEATBAR] = Mp * 256; sz[WS_XCBAR_C] = Mp * 3; sz[WS_GCBAR_C] = Mp * 3; sz[WS_VBAR_C] = Mp * 3;
         }
     }
     size_t o = 0;

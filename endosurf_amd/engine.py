@@ -228,7 +228,7 @@ class Engine:
 
 class PointCtx:
     """Workspace of one fused point evaluation + typed views of its outputs."""
-    _OUT = {"xc": (_lib.WS_XC, 3), "J": (_lib.WS_J, 9), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
+    _OUT = {"xc": (_lib.WS_XC, 3), "v": (_lib.WS_V, 3), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
             "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3)}
 
     def __init__(self, eng: "Engine", pts, flags: int, m_color: int = 0):

@@ -47,8 +47,9 @@ def test_point_forward(mode, use_deform, M, color):
     assert qd(ctx.view("sdf"), pe["sdf"]) < 1e-5
     assert qd(ctx.view("gc"), pe["g_c"]) < 1e-4
     if use_deform:
-        assert qd(ctx.view("J"), pe["J"].reshape(M, 9), 0.99) < 5e-5
-        assert qd(ctx.view("J"), pe["J"].reshape(M, 9)) < 0.5
+        jd = torch.einsum("mik,mk->mi", pe["J"], d.double())             # the kernels carry J d (JVP) and J^T g_c (VJP), not J
+        assert qd(ctx.view("v"), jd, 0.99) < 5e-5
+        assert qd(ctx.view("v"), jd) < 0.5
     assert qd(ctx.view("go"), pe["g_o"], 0.98) < 2e-4
     if color:
         assert qd(ctx.view("feat"), pe["feat"]) < 5e-5
@@ -76,4 +77,5 @@ def test_point_forward_golden(name):
     assert qd(ctx.view("rgb"), g("pt64/rgb"), 0.98) < 5e-5
     if use_deform:
         assert qd(ctx.view("xc") - x, g("pt64/deform")) < 3e-6
-        assert qd(ctx.view("J"), g("pt64/J").reshape(M, 9), 0.99) < 5e-5
+        jd = torch.einsum("mik,mk->mi", g("pt64/J").reshape(M, 3, 3).double(), d.cpu().double())
+        assert qd(ctx.view("v"), jd, 0.99) < 5e-5
