@@ -559,13 +559,18 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
 // -------------------------------------------------------------------------------------------------------------
 // Two-segment launches as in point_fwd.hip: the tail's two dependent stages ride in the halves of the main deformation launch
 //   colour_bwd(main) | sdf_bwd(main) | sdf_bwd(tail) + deform_bwd(main, 1st half) | deform_bwd(tail) + deform_bwd(main, 2nd half)
-enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM, BB_TAN };
+enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM, BB_TAN, BB_TAN_SDF };
 template <int B>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a, int tile) {
     if constexpr (B == BB_COLOR) color_bwd_tile(a, tile);
     else if constexpr (B == BB_SDF) sdf_bwd_tile(a, tile);
     else if constexpr (B == BB_DEFORM) deform_bwd_tile(a, tile);
     else if constexpr (B == BB_TAN) deform_tan_tile(a, tile);
+    else if constexpr (B == BB_TAN_SDF) {      // both stages of a colour-less tile in one workgroup (J gbar_o goes through the workspace)
+        deform_tan_tile(a, tile);
+        __syncthreads();
+        sdf_bwd_tile(a, tile);
+    }
 }
 template <int B0, int B1>
 __global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, int t0, int t1) {
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, in
     bwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
 }
 constexpr int bwd_lds(int b) {
-    return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : (b == BB_TAN ? LEAN_LDS_BYTES : 0)));
+    return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : (b == BB_TAN || b == BB_TAN_SDF ? LEAN_LDS_BYTES : 0)));
 }
 template <int B0, int B1>
 static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
@@ -599,6 +604,18 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
+    if (deform && aux_tail(flags, a.M_color, src.M)) {
+        // tail stages mixed into the main launches as in point_fwd.hip:
+        //   colour_bwd(main) | tan(main) | sdf_bwd(main) | [tan + sdf_bwd](tail) + deform_bwd(main) | deform_bwd(tail)
+        const int Mc = a.M_color;
+        { ScopedTimer tm(KID_COLOR_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_DEFORM_TAN, Mc, st); if (int e = launch_bwd<BB_NONE, BB_TAN>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_DEFORM_BWD, src.M, st);
+          if (int e = launch_bwd<BB_TAN_SDF, BB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, Mc / 32, 0, st)) return e;
+          if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
+        return hip_last("point_backward_chains");
+    }
     if (deform) { ScopedTimer tm(KID_DEFORM_TAN, src.M, st); if (int e = launch_bwd<BB_NONE, BB_TAN>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }

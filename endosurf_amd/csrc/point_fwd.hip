@@ -496,13 +496,18 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
 // kernels (1024 + 48 tiles), which costs a full tile time.  Every main launch of this workload is a whole number of rounds,
 // so extra tiles always cost something -- least inside a launch of MANY short rounds: the tail's two dependent stages
 // (deform, then SDF) are therefore mixed into the two halves of the 8-round deformation launch of the main tiles.
-enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP };
+enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP, FB_SDF_VJP };
 template <int B>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
     if constexpr (B == FB_DEFORM) deform_fwd_tile(a, tile);
     else if constexpr (B == FB_SDF) sdf_fwd_tile(a, tile);
     else if constexpr (B == FB_COLOR) color_fwd_tile(a, tile);
     else if constexpr (B == FB_VJP) deform_vjp_tile(a, tile);
+    else if constexpr (B == FB_SDF_VJP) {      // both stages of a colour-less tile in one workgroup (g_c goes through the workspace)
+        sdf_fwd_tile(a, tile);
+        __syncthreads();
+        deform_vjp_tile(a, tile);
+    }
 }
 template <int B0, int B1>
 __global__ __launch_bounds__(NTHREADS, 2) void k_point_fwd(FwdArgs a, int n0, int t0, int t1) {
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_point_fwd(FwdArgs a, int n0, in
     }
     fwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
 }
-constexpr int fwd_lds(int b) { return b == FB_COLOR ? CFWD_LDS_BYTES : (b == FB_NONE ? 0 : LEAN_LDS_BYTES); }
+constexpr int fwd_lds(int b) { return b == FB_COLOR ? CFWD_LDS_BYTES : (b == FB_NONE ? 0 : LEAN_LDS_BYTES); }   // SBWD <= LEAN
 template <int B0, int B1>
 static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
     constexpr int lds = fwd_lds(B0) > fwd_lds(B1) ? fwd_lds(B0) : fwd_lds(B1);
@@ -534,6 +539,20 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
+    if (deform && aux_tail(flags, a.M_color, src.M)) {
+        // main tiles [0, Mc), colour-less tail [Mc, Mp).  Every main launch is a whole number of rounds of the 512 workgroup
+        // slots, so the tail's few tiles (whose three stages depend on each other) cost least where they overlap a launch of
+        // many short rounds or a launch of longer tiles:
+        //   deform(tail) | [sdf + vjp](tail) + deform(main) | sdf(main) | colour(main) | vjp(main)
+        const int Mc = a.M_color;
+        { ScopedTimer tm(KID_DEFORM_FWD, src.M, st);
+          if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e;
+          if (int e = launch_fwd<FB_SDF_VJP, FB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, Mc / 32, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_DEFORM_VJP, Mc, st); if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        return hip_last("point_forward");
+    }
     if (deform) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mp / 32, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
