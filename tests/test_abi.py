@@ -67,7 +67,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.es_composite_args) % 8 == 0
     assert lib.es_point_workspace_floats(0, 7) == 0
     n = lib.es_point_workspace_floats(100, 7)
-    assert n > 128 * 20000 and lib.es_point_workspace_offset(100, 7, 2) >= 128 * 12
+    assert n > 128 * 20000 and lib.es_point_workspace_offset(100, 7, 2) >= 128 * 6      # x_c (3) and v = J d (3) precede the sdf buffer
     assert lib.es_kernel_name(0) == b"k_query_sdf"
 
 

@@ -27,10 +27,11 @@ def agg(d):
 
 
 # the chain kernels are instantiations of two dispatcher templates (point_fwd.hip / point_bwd.hip): <B0, B1> = (tail body, main body)
-LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<1, 1>": "k_deform_fwd", "k_point_fwd<2, 1>": "k_deform_fwd",
-           "k_point_fwd<0, 2>": "k_sdf_fwd", "k_point_fwd<0, 3>": "k_color_fwd", "k_point_bwd<0, 1>": "k_color_bwd",
-           "k_point_bwd<0, 2>": "k_sdf_bwd", "k_point_bwd<0, 3>": "k_deform_bwd", "k_point_bwd<2, 3>": "k_deform_bwd",
-           "k_point_bwd<3, 3>": "k_deform_bwd"}
+# body ids: fwd 1 deform (value + J d), 2 sdf, 3 colour, 4 vjp, 5 sdf+vjp (tail); bwd 1 colour, 2 sdf, 3 deform, 4 tan, 5 tan+sdf (tail)
+LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<5, 1>": "k_deform_fwd", "k_point_fwd<0, 2>": "k_sdf_fwd",
+           "k_point_fwd<0, 3>": "k_color_fwd", "k_point_fwd<0, 4>": "k_deform_vjp", "k_point_bwd<0, 1>": "k_color_bwd",
+           "k_point_bwd<0, 2>": "k_sdf_bwd", "k_point_bwd<0, 3>": "k_deform_bwd", "k_point_bwd<5, 3>": "k_deform_bwd",
+           "k_point_bwd<0, 4>": "k_deform_tan"}
 a, f, w = agg(d_sq), agg(d_f), agg(d_w)
 out = []
 for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
