@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
 // the adjoint rows go through LDS once, then all 32 row loads of X are in flight together (pure HBM stream over X).
 // dA == nullptr means dA = 1 (column sums of X).
 constexpr int WS_ROWS = 32;       // rows per inner step (all loads in flight together)
-constexpr int WS_STEPS = 16;      // steps per block: one set of atomics per 512 rows keeps same-address contention low
+constexpr int WS_STEPS = 4;       // steps per block (128 rows): enough blocks to keep every CU streaming
 __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X, int ldx, const float* __restrict__ dA, int lda, int M, int K,
                                                      int N, float* __restrict__ out, int ldo, float* __restrict__ bias_out, int bias_stride) {
     __shared__ float sd[2][WS_ROWS][4];
