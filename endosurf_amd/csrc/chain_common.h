@@ -24,12 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TM = 64;                     // rows per workgroup tile
 constexpr int NTHREADS = 256;              // 4 wavefronts
 constexpr int MAIN_FLOATS = HID * TM;      // 64 KiB main activation tile
-constexpr int AUX_K = 128;
-constexpr int AUX_FLOATS = AUX_K * TM;     // 32 KiB auxiliary tile (encodings / small skip inputs / small adjoints)
-constexpr int SCR_FLOATS = 2048;           // 8 KiB scratch
-constexpr int LDS_FLOATS = MAIN_FLOATS + AUX_FLOATS + SCR_FLOATS;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;  // 106 496 B of the 160 KiB per CU
-// Lean carve used by the kernels that fit two workgroups per CU (<= 80 KiB each, <= 256 registers per lane):
+// LDS carve of the chain kernels: two workgroups per CU (<= 80 KiB each, <= 256 registers per lane):
 // activation tile | 56-row auxiliary tile (encodings; reused as reduction scratch once consumed) | 1 KiB of per-row data
 constexpr int AUX56_FLOATS = 56 * TM;
 constexpr int LEAN_LDS_BYTES = (MAIN_FLOATS + AUX56_FLOATS + 256) * 4;   // 80 896 B
