@@ -93,3 +93,35 @@ def test_training_step_full_size_is_finite_and_moves_parameters():
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and all(np.isfinite(float(v)) for v in terms.values())
     assert bool(torch.isfinite(r.model._flat).all()) and float((r.model._flat - before).abs().max()) > 1e-4
+
+
+def test_config3_2048_rays_128_samples_eikonal_and_step():
+    """BASELINE config 3: 2048 rays x (64 + 64) samples (262 144 + 6 144 points per launch) with the eikonal output checked, and
+    config 4's network (use_deform = False) on a 1024-ray training step."""
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+    from gpu_util import RENDER_CFG
+    cfg3 = dict(RENDER_CFG, n_samples=64, n_importance=64)
+    r = renderer_for(31, "trained", True, render_cfg=cfg3)
+    b = SyntheticScene("cuda", seed=15).batch(2048)
+    with torch.no_grad():
+        out = r(b["rays"], iter_step=20000, perturb_overwrite=False)
+    assert tuple(out["weights"].shape) == (2048, 128) and tuple(out["gradients_o"].shape) == (2048, 128, 3)
+    # eikonal term = masked mean of (|g_o| - 1)^2 over the samples inside the unit sphere (endosurf.py:199-203)
+    g = out["gradients_o"]
+    z = r.sample_z(b["rays"], 20000, perturb_overwrite=False)
+    sd = 2.0 / 64
+    mid = z + torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sd)], -1) * 0.5
+    d = b["rays"][:, 3:6]
+    pts = b["rays"][:, None, :3] + (d / (d[:, 2:] + 1e-6))[:, None, :] * mid[..., None]
+    inside = (pts.norm(dim=-1) < 1.0).float()
+    eik = (((g.norm(dim=-1) - 1.0) ** 2) * inside).sum() / (inside.sum() + 1e-6)
+    assert abs(float(eik) - float(out["gradient_o_error"])) < 1e-4 * max(1.0, float(eik))
+    tr = Trainer(r, warm_up_end=1)
+    loss, terms, _ = tr.train_step(b, 20000)
+    assert np.isfinite(float(loss)) and bool(torch.isfinite(r.model._flat).all())
+    # config 4: no deformation network
+    r4 = renderer_for(32, "trained", False)
+    tr4 = Trainer(r4, warm_up_end=1)
+    before = r4.model._flat.clone()
+    loss4, _, _ = tr4.train_step(_scene(16), 60000)
+    assert np.isfinite(float(loss4)) and float((r4.model._flat - before).abs().max()) > 1e-5
