@@ -1,11 +1,13 @@
 // K6: hand-written backward of the fused point evaluation (the reference gets it from autograd with
 // create_graph=True double-backward, endosurf.py:598, 616, 640-656).  Given adjoints of (sdf, g_o, rgb) per point:
 //   color_bwd   reverse sweep through ColorNetwork -> adjoints of its pre-activations (for the weight-gradient GEMMs)
-//               and of its inputs: x_c (via enc10), g_c, d_c -> J (via normalize(J d)), feat
+//               and of its inputs: x_c (via enc10), g_c, d_c -> v = J d (via normalize), feat
 //   sdf_bwd     (i) forward tangent sweep along gbar_c: the adjoint of the reverse-mode input gradient g_c is a
 //               forward-mode directional derivative; yields tau_l and the second-order terms 100(1-phi')rho_l pi_l
 //               (softplus''); (ii) ordinary reverse sweep of the value pass seeded with [sdfbar, featbar]
-//   deform_bwd  reverse sweep on 4 rows per point (value row seeded with xbar_c, tangent rows with Jbar); ReLU'' = 0
+//   deform_tan  forward tangent sweep of the deformation network along gbar_o: g_o = J^T g_c is linear in g_c with
+//               adjoint J gbar_o (consumed by sdf_bwd) and linear in every W_l (pairs (tau_l, r_l) with the VJP sweep's r_l)
+//   deform_bwd  reverse sweep on 2 rows per point (value row seeded with xbar_c, J d row with vbar); ReLU'' = 0
 // Weight gradients are formed afterwards by wgrad.hip from the streamed (input, adjoint) pairs.
 #include "chain_common.h"
 #include "encode.h"

@@ -1,9 +1,10 @@
 // K4 forward: per-point network evaluation of EndoSurfNet.forward (reference endosurf.py:660-689) and
-// get_sdf_grad_from_observed_space (:581-601), restructured so that every MLP runs once:
-//   deform_fwd  DeformNetwork (:724-738) on 4 rows per point: value + 3 forward-mode tangents -> x_c and the
-//               3x3 Jacobian J = d x_c / d x  (replaces 3 forward + 4 autograd sweeps of :621-658, :581-601)
-//   sdf_fwd     SDFNetwork (:773-786) value pass (sdf, 256 features) + analytic reverse sweep for
-//               g_c = d sdf / d x_c (:603-619), then g_o = J^T g_c (identical to :581-601 up to rounding)
+// get_sdf_grad_from_observed_space (:581-601), restructured so that no network pass is repeated:
+//   deform_fwd  DeformNetwork (:724-738) on 2 rows per point: value + forward-mode tangent along the ray direction
+//               -> x_c and J d (the reference builds the full 3x3 Jacobian with 3 autograd sweeps, :621-658, only to form J d)
+//   sdf_fwd     SDFNetwork (:773-786) value pass (sdf, 256 features) + analytic reverse sweep for g_c = d sdf / d x_c (:603-619)
+//   deform_vjp  reverse sweep of the deformation network for the covector g_c -> g_o = J^T g_c (identical to :581-601 up
+//               to rounding)
 //   color_fwd   ColorNetwork (:828-842) on [enc10(x_c), g_c, enc4(normalize(J d)), feat] -> sigmoid rgb
 // With PF_SAVE the layer inputs / reverse adjoints are streamed to the workspace for the backward pass.
 #include "chain_common.h"

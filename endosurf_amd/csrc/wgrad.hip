@@ -1,10 +1,9 @@
 // Weight-gradient GEMMs of the backward pass:  dW[n][k] += sum_m dA[m][n] * X[m][k]  for every layer, from the
 // (layer input X, pre-activation adjoint dA) pairs streamed to the workspace by the forward/backward chains.
-// All problems of one network are batched in ONE launch (grouped GEMM): independent wavefront tasks
-// (problem, 64x64 output tile, row chunk), operands loaded global->VGPR as float2 (two MFMA fragments per load,
-// feature-interleaved), contraction on v_mfma_f32_32x32x2_f32, results reduced with fp32 atomics (few row chunks per
-// output tile because the layer dimension supplies the parallelism).  Bias gradients are column sums of dA taken on
-// the fly by the k-block-0 tasks.
+// All problems of one network are batched in ONE launch (grouped GEMM): independent workgroup tasks (problem, 256 x 128
+// tile of dW, row chunk) whose operand panels are staged through LDS, contraction on v_mfma_f32_32x32x2_f32, results reduced
+// with fp32 atomics (few row chunks per output tile).  Bias gradients are column sums of dA taken on the fly by the
+// k-block-0 tasks.
 #include <hip/hip_runtime.h>
 
 #include "arch.h"
