@@ -153,9 +153,8 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        gc, gd, ge, gs, gg = ctx.grads
-        return (gc * g_total, gd * g_total, (ge * g_total).reshape(ctx.eik_shape), gs * g_total, gg * g_total,
-                None, None, None, None, None, None, None, None, None)
+        gc, gd, ge, gs, gg = torch._foreach_mul(ctx.grads, g_total)       # one multi-tensor launch
+        return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None)
 
 
 def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
