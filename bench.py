@@ -44,9 +44,13 @@ def flops_per_ray_forward(S_c=32, S_i=32, steps=4):
     return f_up, f_core
 
 
-def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=20):
+def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
     """The oracle (CPU restatement of the reference op sequence, torch-CPU fp32 + autograd) timed on this box's host cores
-    on a bounded sample of the same workload: full training steps at ``n_rays`` rays."""
+    on a bounded sample of the same workload: full training steps at ``n_rays`` rays.  16 intra-op threads: at these tensor
+    sizes (8 192 points x 256 features per GEMM) torch-CPU is fastest there (measured 8/16/32/64/128 threads on the 2 x 64-core
+    host: 180 / 213 / 147 / 73 / 26 rays/s); ``cores`` reports the threads actually used."""
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, max(1, os.cpu_count() or threads)))
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import numpy as np
     import weightgen
@@ -74,7 +78,9 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=20):
         step()
         it += 1
     dt = (time.perf_counter() - t0) / it
-    return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+    cores = torch.get_num_threads()
+    torch.set_num_threads(prev_threads)
+    return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
                 sample=f"{it} full training steps of the CPU oracle at {n_rays} rays x 64 samples (torch-CPU fp32, autograd), {dt:.2f} s/step")
 
 
