@@ -218,6 +218,26 @@ __device__ __forceinline__ void load_tile_256(float* At, const float* __restrict
     load_tile<256>(At, src, grow0, ld, tid);
 }
 
+// ---- ReLU masks of the deformation network as bit words ------------------------------------------------
+// deform_fwd (tile = 32 points, rows [value, tangent] per point) writes one uint32 per thread and layer: bit 2*qi + v is the
+// mask of value row v (quad rows 0 / 2) of quad qi = (ri*2 + ni)*4 + q.  A 64-point tile of the one-row-per-point sweeps
+// (VJP, tangent) covers two such tiles; its lane (lo, hi) needs, per layer, the words of producer lanes (lo, 0) and (lo, 1)
+// of both: point 32*ri_c + 8*q_c + 4*hi + i is producer row 2*(8*q_c + 4*hi + i) = quad (q_c>>1, ., 2*(q_c&1) + hi) of
+// producer lane hi' = i>>1, value row i&1.
+struct MaskWords { unsigned w[2][2]; };      // [ri_c][producer hi]
+__device__ __forceinline__ MaskWords load_mask_words(const unsigned* __restrict__ Ml, int tile64, int wave, int lane) {
+    MaskWords m;
+    const unsigned* p = Ml + (size_t)(2 * tile64) * 256 + wave * 64 + (lane & 31);
+    m.w[0][0] = p[0]; m.w[0][1] = p[32]; m.w[1][0] = p[256]; m.w[1][1] = p[256 + 32];
+    return m;
+}
+// mask of element i of consumer quad qi = (ri_c*2 + ni)*4 + q_c for a lane with hi = lane>>5
+__device__ __forceinline__ bool mask_bit(const MaskWords& m, int qi, int i, int hi) {
+    const int ri_c = qi >> 3, ni = (qi >> 2) & 1, q_c = qi & 3;
+    const int pq = ((q_c >> 1) * 2 + ni) * 4 + 2 * (q_c & 1) + hi;
+    return (m.w[ri_c][i >> 1] >> (2 * pq + (i & 1))) & 1u;
+}
+
 // ---- activations ---------------------------------------------------------------------------------
 // nn.Softplus(beta=100, threshold=20)  (reference endosurf.py:771):  z if 100z > 20 else log1p(exp(100z))/100.
 // Evaluated branch-free as max(z,0) + log(1 + exp(-|100z|))/100 on the hardware exp/log units: identical above

@@ -415,7 +415,9 @@ __device__ __forceinline__ void deform_tan_tile(const BwdArgs& a, const int tile
     const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
     const size_t Mp = (size_t)a.L.Mp;
-    const float* U = wsb(a, WS_D_U);         // value row of point r = row 2r  ->  leading dimension 512
+    const unsigned* MK = reinterpret_cast<const unsigned*>(wsb(a, WS_D_MASK));
+    const size_t nt32 = Mp / 32;
+    const int hi = lane >> 5;
     float* T = wsb(a, WS_D_T);
 
     if (tid < 64) {
@@ -450,36 +452,35 @@ __device__ __forceinline__ void deform_tan_tile(const BwdArgs& a, const int tile
         const int r = tid >> 2, c4 = tid & 3;
         for (int k = c4; k < 56; k += 4) T0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* Ul = U + (size_t)l * 2 * Mp * 256;
+    auto epi = [&](f32x16(&acc)[2][2], int l, const MaskWords& mk) {
         float* Tl = T + (size_t)l * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             if (l == 3 && col >= 204) {
                 lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
             } else {
-                float m[4];
-                g_load_quad(Ul, grow0, 512, row, col, m);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
             }
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Tl, grow0, 256, row, col, v);
         });
     };
     {
+        const MaskWords mk = load_mask_words(MK, tile, wave, lane);
         f32x16 acc[2][2];
         acc_zero(acc);
         gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
-        epi(acc, 0);
+        epi(acc, 0, mk);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
+        const MaskWords mk = load_mask_words(MK + (size_t)l * nt32 * 256, tile, wave, lane);          // in flight during the GEMM
         f32x16 acc[2][2];
         acc_zero(acc);
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l);
+        epi(acc, l, mk);
         __syncthreads();
     }
     smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
@@ -518,14 +519,16 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
         A8[3] = 0.f;
     }
     __syncthreads();
-    const float* U = wsb(a, WS_D_U);
+    const unsigned* MK = reinterpret_cast<const unsigned*>(wsb(a, WS_D_MASK));
+    const size_t nt32 = (size_t)a.L.Mp / 32;
     float* DA = wsb(a, WS_D_A);
     {   // abar_7 = mask_7 * (W8^T abar_8)
         const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
-        const float* U7 = U + (size_t)7 * rows2 * 256;
+        const unsigned bits = MK[((size_t)7 * nt32 + tile) * 256 + tid];        // this thread's own word of the forward tile
         for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
             const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
-            const bool m0 = U7[(grow0 + row) * 256 + col] > 0.f, m2 = U7[(grow0 + row + 2) * 256 + col] > 0.f;   // value rows
+            const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
+            const bool m0 = (bits >> (2 * qi)) & 1u, m2 = (bits >> (2 * qi + 1)) & 1u;   // value rows
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (i < 2 ? m0 : m2) ? a8[row + i] * w0 + a8[64 + row + i] * w1 + a8[128 + row + i] * w2 : 0.f;
@@ -536,10 +539,7 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-        const float* Ul = U + (size_t)(l - 1) * rows2 * 256;
-        float upre[16], upre2[16];                                                    // value-row activations, in flight during the GEMM
-        prefetch_quad_heads<2, 2>(upre, Ul, grow0, 256, 0, 2 * wave, lane);
-        prefetch_quad_heads<2, 2>(upre2, Ul, grow0 + 2, 256, 0, 2 * wave, lane);
+        const unsigned bits = MK[((size_t)(l - 1) * nt32 + tile) * 256 + tid];        // in flight during the GEMM
         f32x16 acc[2][2];
         acc_zero(acc);
         if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
@@ -549,7 +549,7 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
         for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             // layer 3 has 204 outputs: the skip's encoding part (cols >= 204) carries no parameter gradient
             const bool dead = l == 4 && col >= 204;
-            const bool m0 = !dead && upre[qi] > 0.f, m2 = !dead && upre2[qi] > 0.f;
+            const bool m0 = !dead && ((bits >> (2 * qi)) & 1u), m2 = !dead && ((bits >> (2 * qi + 1)) & 1u);
             v[0] = m0 ? v[0] : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? v[2] : 0.f; v[3] = m2 ? v[3] : 0.f;
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Al, grow0, 256, row, col, v);

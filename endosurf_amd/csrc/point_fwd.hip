@@ -91,10 +91,13 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     }
 
     float* U = wsb(a, WS_D_U);
+    unsigned* MK = reinterpret_cast<unsigned*>(wsb(a, WS_D_MASK));
+    const size_t nt32 = (size_t)a.L.Mp / 32;
     auto epi = [&](f32x16(&acc)[2][2], int l) {
         const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l];
         float* Ul = U + (size_t)l * rows2 * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {       // rows: value, tangent, value, tangent
+        unsigned bits = 0;
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {       // rows: value, tangent, value, tangent
             if (l == 3 && col >= 204) {
                 lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
             } else {
@@ -102,11 +105,12 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
                 const float a0 = v[0] + b, a2 = v[2] + b;
                 const bool m0 = a0 > 0.f, m2 = a2 > 0.f;         // the ReLU mask of a value row gates its tangent
                 v[0] = m0 ? a0 : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? a2 : 0.f; v[3] = m2 ? v[3] : 0.f;
+                bits |= (m0 ? 1u : 0u) << (2 * qi) | (m2 ? 1u : 0u) << (2 * qi + 1);
             }
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(Ul, grow0, 256, row, col, v);
-            else { Ul[(grow0 + row) * 256 + col] = v[0]; Ul[(grow0 + row + 2) * 256 + col] = v[2]; }
         });
+        MK[((size_t)l * nt32 + tile) * 256 + tid] = bits;        // the masks of the VJP / tangent / reverse sweeps
     };
     {
         f32x16 acc[2][2];
@@ -152,7 +156,9 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     const size_t grow0 = (size_t)row0;
     const bool save = a.flags & PF_SAVE;
     const size_t Mp = (size_t)a.L.Mp;
-    const float* U = wsb(a, WS_D_U);         // [8][2Mp][256]: value row of point r = row 2r  ->  leading dimension 512
+    const unsigned* MK = reinterpret_cast<const unsigned*>(wsb(a, WS_D_MASK));
+    const size_t nt32 = Mp / 32;
+    const int hi = lane >> 5;
     float* R = wsb(a, WS_D_R);
 
     if (tid < 64) {
@@ -163,13 +169,13 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     __syncthreads();
     {   // r_7 = mask_7 * (W8^T g_c)
         const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
-        const float* U7 = U + (size_t)7 * 2 * Mp * 256;
+        const MaskWords mk = load_mask_words(MK + (size_t)7 * nt32 * 256, tile, wave, lane);
         for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
             const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
-            float m[4], v[4];
-            g_load_quad(U7, grow0, 512, row, col, m);
+            const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
+            float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? g8[row + i] * w0 + g8[64 + row + i] * w1 + g8[128 + row + i] * w2 : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? g8[row + i] * w0 + g8[64 + row + i] * w1 + g8[128 + row + i] * w2 : 0.f;
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(R + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
         });
@@ -177,23 +183,21 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
+        const MaskWords mk = load_mask_words(MK + (size_t)(l - 1) * nt32 * 256, tile, wave, lane);     // in flight during the GEMM
         f32x16 acc[2][2];
         acc_zero(acc);
         if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
         else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
         __syncthreads();
-        const float* Ul = U + (size_t)(l - 1) * 2 * Mp * 256;
         float* Rl = R + (size_t)(l - 1) * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             if (l == 4 && col >= 204) {
                 lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
             } else {
-                float m[4];
-                g_load_quad(Ul, grow0, 512, row, col, m);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
             }
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(Rl, grow0, 256, row, col, v);

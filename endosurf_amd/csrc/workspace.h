@@ -21,7 +21,9 @@ enum WsBuf : int {
     // forward saves
     WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them)
     WS_D_U0,       // [2Mp][64]     deform encoding rows (52 valid)
-    WS_D_U,        // [8][2Mp][256] u_1..u_8 (always written: the value rows are the ReLU masks of the VJP / tangent sweeps)
+    WS_D_U,        // [8][2Mp][256] u_1..u_8 (for the weight-gradient GEMMs)
+    WS_D_MASK,     // [8][Mp/32][256] uint32: ReLU masks of the value rows, one word per (32-point tile, thread) in the
+                   //               accumulator-fragment order of deform_fwd (bit 2*quad + {0,1}); always written
     WS_D_R,        // [8][Mp][256]  VJP sweep: adjoints r_0..r_7 of the pre-activations for the covector g_c
     WS_S_S0,       // [Mp][64]      enc6(x_c) (39 valid)
     WS_S_RHO,      // [8][Mp][256]  d sdf / d z_0..7
@@ -60,13 +62,13 @@ inline WsLayout ws_layout(int M, int flags) {
     const bool def = flags & PF_DEFORM, col = flags & PF_COLOR, save = flags & PF_SAVE;
     size_t sz[WS_COUNT] = {0};
     sz[WS_XC] = Mp * 3; sz[WS_V] = Mp * 3; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
-    sz[WS_D_U] = def ? 8 * 2 * Mp * 256 : 0;
+    sz[WS_D_MASK] = def ? 8 * (Mp / 32) * 256 : 0;
     sz[WS_FEAT] = col ? Mp * 256 : 0; sz[WS_RGB] = col ? Mp * 3 : 0;
     sz[WS_C_IN] = col ? Mp * 128 : 0;      // always: the colour kernel re-stages it at the skip layer
     sz[WS_S_ACT] = 8 * Mp * 256;
     if (save) {
         if (def) {
-            sz[WS_D_U0] = 2 * Mp * 64; sz[WS_D_A] = 8 * 2 * Mp * 256; sz[WS_D_A8] = 2 * Mp * 4;
+            sz[WS_D_U0] = 2 * Mp * 64; sz[WS_D_U] = 8 * 2 * Mp * 256; sz[WS_D_A] = 8 * 2 * Mp * 256; sz[WS_D_A8] = 2 * Mp * 4;
             sz[WS_D_R] = 8 * Mp * 256; sz[WS_JU] = Mp * 3; sz[WS_D_T0] = Mp * 64; sz[WS_D_T] = 8 * Mp * 256;
         }
         sz[WS_S_S0] = Mp * 64; sz[WS_S_RHO] = 8 * Mp * 256; sz[WS_S_ADJEPS] = Mp * 64;
