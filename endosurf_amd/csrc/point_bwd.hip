@@ -106,32 +106,31 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
     }
     __syncthreads();
-    const float* CH = wsb(a, WS_C_H);
+    const unsigned long long* CM = reinterpret_cast<const unsigned long long*>(wsb(a, WS_C_MASK));   // this thread's own words
+    const size_t nt64 = Mp / 64;
     float* CY = wsb(a, WS_C_Y);
     {   // ybar_7 = relu'(y_7) * (U8^T ybar_8)
         const float* U8 = a.weff + a.tb.woff[NET_C * LAYERS + 8];
+        const unsigned long long bits = CM[((size_t)7 * nt64 + tile) * 256 + tid];
         for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
             const float u0 = U8[col], u1 = U8[256 + col], u2 = U8[512 + col];
-            float h[4], v[4];
-            g_load_quad(CH + (size_t)7 * Mp * 256, grow0, 256, row, col, h);
+            const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
+            float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float hb = y8[row + i] * u0 + y8[64 + row + i] * u1 + y8[128 + row + i] * u2;
-                v[i] = h[i] > 0.f ? hb : 0.f;
+                v[i] = ((bits >> (4 * qi + i)) & 1ull) ? hb : 0.f;
             }
             lds_store_quad(mainT, col, row, v);
             g_store_quad(CY + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
         });
     }
     __syncthreads();
-    auto epi = [&](f32x16(&acc)[2][2], int l) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
-        const float* Hl = CH + (size_t)(l - 1) * Mp * 256;
+    auto epi = [&](f32x16(&acc)[2][2], int l, unsigned long long bits) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
         float* Yl = CY + (size_t)(l - 1) * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float h[4];
-            g_load_quad(Hl, grow0, 256, row, col, h);          // latency covered by the co-resident workgroup
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = h[i] > 0.f ? v[i] : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = ((bits >> (4 * qi + i)) & 1ull) ? v[i] : 0.f;
             lds_store_quad(mainT, col, row, v);
             g_store_quad(Yl, grow0, 256, row, col, v);
         });
@@ -140,6 +139,7 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
     float* SB = wsb(a, WS_C_SBAR);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
+        const unsigned long long bits = CM[((size_t)(l - 1) * nt64 + tile) * 256 + tid];      // in flight during the GEMMs
         if (l == 4) {   // skip layer: adjoint also flows to the network input [small(93) | feat(256)]
             {
                 f32x16 accF[2][2];
@@ -159,7 +159,7 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         const int seg = l < 4 ? CR1 + (l - 1) : (l == 4 ? (int)CR4H : CR5 + (l - 5));
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l);
+        epi(acc, l, bits);
         __syncthreads();
     }
     {   // layer 0: adjoint of the network input

@@ -443,13 +443,19 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
     auto epi = [&](f32x16(&acc)[2][2], int l) {
         const float* bias = a.weff + a.tb.boff[NET_C * LAYERS + l];
         float* Hl = CH + (size_t)l * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        unsigned long long bits = 0;
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
             const float b = bias[col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+            for (int i = 0; i < 4; ++i) {
+                v[i] = fmaxf(v[i] + b, 0.f);
+                bits |= (unsigned long long)(v[i] > 0.f) << (4 * qi + i);
+            }
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(Hl, grow0, 256, row, col, v);
         });
+        if (save)      // the ReLU masks of the backward sweep: 2 words per thread instead of 64 activations
+            reinterpret_cast<unsigned long long*>(wsb(a, WS_C_MASK))[((size_t)l * (Mp / 64) + tile) * 256 + tid] = bits;
     };
     {
         f32x16 acc[2][2];

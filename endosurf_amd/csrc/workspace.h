@@ -30,6 +30,8 @@ enum WsBuf : int {
     WS_S_ADJEPS,   // [Mp][64]      d sdf / d enc6(x_c)
     WS_C_IN,       // [Mp][128]     colour input small part (93 valid)
     WS_C_H,        // [8][Mp][256]  h_1..h_8
+    WS_C_MASK,     // [8][Mp/64][512] uint32: ReLU masks of h_1..h_8, two words per (tile, thread) in accumulator-fragment
+                   //               order (bit 4*quad + row); colour_fwd and colour_bwd share the tile geometry
     // backward buffers
     WS_C_Y,        // [8][Mp][256]  adjoints of colour pre-activations y_0..7
     WS_C_Y8,       // [Mp][4]
@@ -75,7 +77,7 @@ inline WsLayout ws_layout(int M, int flags) {
         sz[WS_S_TAU0] = Mp * 64; sz[WS_S_TAU] = 8 * Mp * 256; sz[WS_S_ZB] = 8 * Mp * 256;
         sz[WS_XCBAR] = Mp * 3;
         if (col) {
-            sz[WS_C_SBAR] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
+            sz[WS_C_SBAR] = Mp * 128; sz[WS_C_H] = 8 * Mp * 256; sz[WS_C_MASK] = 8 * (Mp / 64) * 512; sz[WS_C_Y] = 8 * Mp * 256; sz[WS_C_Y8] = Mp * 4;
             sz[WS_FEATBAR] = Mp * 256; sz[WS_XCBAR_C] = Mp * 3; sz[WS_GCBAR_C] = Mp * 3; sz[WS_VBAR_C] = Mp * 3;
         }
     }
