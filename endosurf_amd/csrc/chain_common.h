@@ -165,6 +165,32 @@ __device__ __forceinline__ void prefetch_quads(float (&buf)[RTC * NTC * 4][4], c
                 b[0] = p[0]; b[1] = p[ld]; b[2] = p[2 * ld]; b[3] = p[3 * ld];
             }
 }
+// The 8 quads (ri, q) of ONE n-tile column block ni of a 64 x 64 wave tile: batch index b8 = ri*4 + q.  Epilogues that read
+// saved activations issue all loads of a half (8 quads per operand = 32 registers) before they touch the first value, so an
+// epilogue pays two memory round trips in total instead of one per compiler-chosen group of quads.
+template <int NI>
+__device__ __forceinline__ void prefetch_half(float (&buf)[8][4], const float* __restrict__ base, size_t grow0, int ld, int nt0, int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* p = base + (grow0 + ri * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + NI) * 32 + lo;
+            float(&b)[4] = buf[ri * 4 + q];
+            b[0] = p[0]; b[1] = p[ld]; b[2] = p[2 * ld]; b[3] = p[3 * ld];
+        }
+}
+template <int NI, class F>
+__device__ __forceinline__ void for_quads_half(f32x16 (&acc)[2][2], int nt0, int lane, F&& f) {      // f(row, col, v, b8)
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4] = {acc[ri][NI][4 * q + 0], acc[ri][NI][4 * q + 1], acc[ri][NI][4 * q + 2], acc[ri][NI][4 * q + 3]};
+            f(ri * 32 + 8 * q + 4 * hi, (nt0 + NI) * 32 + lo, v, ri * 4 + q);
+        }
+}
 // one value per quad (first row of the quad): ReLU masks of the deformation network's value rows
 template <int RTC, int NTC>
 __device__ __forceinline__ void prefetch_quad_heads(float (&buf)[RTC * NTC * 4], const float* __restrict__ base, size_t grow0, int ld,

@@ -9,6 +9,8 @@
 //               adjoint J gbar_o (consumed by sdf_bwd) and linear in every W_l (pairs (tau_l, r_l) with the VJP sweep's r_l)
 //   deform_bwd  reverse sweep on 2 rows per point (value row seeded with xbar_c, J d row with vbar); ReLU'' = 0
 // Weight gradients are formed afterwards by wgrad.hip from the streamed (input, adjoint) pairs.
+#include <type_traits>
+
 #include "chain_common.h"
 #include "encode.h"
 #include "launch.h"
@@ -279,20 +281,25 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     // ---- (i) forward tangent sweep ----
     // (epilogue operands are loaded in the epilogue: the co-resident workgroup's MFMAs cover the HBM latency)
     auto epi_t = [&](f32x16(&acc)[2][2], int l) {   // acc = pi_l
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4], r[4], z2[4];
-            g_load_quad(SACT + (size_t)l * Mp * 256, grow0, 256, row, col, s);
-            g_load_quad(RHO + (size_t)l * Mp * 256, grow0, 256, row, col, r);
+        auto half = [&](auto NI) {
+            float S[8][4], Rr[8][4];
+            prefetch_half<decltype(NI)::value>(S, SACT + (size_t)l * Mp * 256, grow0, 256, 2 * wave, lane);
+            prefetch_half<decltype(NI)::value>(Rr, RHO + (size_t)l * Mp * 256, grow0, 256, 2 * wave, lane);
+            for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
+                float z2[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float dphi = softplus100_grad_from_s(s[i]);
-                z2[i] = 100.f * (1.f - dphi) * r[i] * v[i];             // softplus'' / softplus' = 100 (1 - softplus')
-                v[i] = dphi * v[i];                                     // tau_{l+1}
-            }
-            lds_store_quad(mainT, col, row, v);
-            g_store_quad(TAU + (size_t)l * Mp * 256, grow0, 256, row, col, v);
-            g_store_quad(ZB + (size_t)l * Mp * 256, grow0, 256, row, col, z2);
-        });
+                for (int i = 0; i < 4; ++i) {
+                    const float dphi = softplus100_grad_from_s(S[b8][i]);
+                    z2[i] = 100.f * (1.f - dphi) * Rr[b8][i] * v[i];        // softplus'' / softplus' = 100 (1 - softplus')
+                    v[i] = dphi * v[i];                                     // tau_{l+1}
+                }
+                lds_store_quad(mainT, col, row, v);
+                g_store_quad(TAU + (size_t)l * Mp * 256, grow0, 256, row, col, v);
+                g_store_quad(ZB + (size_t)l * Mp * 256, grow0, 256, row, col, z2);
+            });
+        };
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
     };
     {
         f32x16 acc[2][2];
@@ -314,15 +321,19 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     }
     // ---- (ii) reverse sweep of the value pass, seeded with zbar_8 = [sdfbar | featbar] ----
     auto epi_b = [&](f32x16(&acc)[2][2], int l) {   // acc = sbar_l; zbar_{l-1} = phi'(z_{l-1}) sbar_l + second-order term
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4], z2[4];
-            g_load_quad(SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, s);
-            g_load_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, z2);
+        auto half = [&](auto NI) {
+            float S[8][4], Z2[8][4];
+            prefetch_half<decltype(NI)::value>(S, SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, 2 * wave, lane);
+            prefetch_half<decltype(NI)::value>(Z2, ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, 2 * wave, lane);
+            for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
-            lds_store_quad(mainT, col, row, v);
-            g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
-        });
+                for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(S[b8][i]) * v[i] + Z2[b8][i];
+                lds_store_quad(mainT, col, row, v);
+                g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
+            });
+        };
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
     };
     {
         f32x16 acc[2][2];

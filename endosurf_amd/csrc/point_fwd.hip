@@ -340,12 +340,12 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
             acc_zero(accA);
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
         }
+        float S[16][4];                                          // all 16 quads requested at once: one memory round trip
+        prefetch_quads<2, 2>(S, Sl, grow0, 256, 0, 2 * wave, lane);
         __syncthreads();
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            float s[4];
-            g_load_quad(Sl, grow0, 256, row, col, s);          // the co-resident workgroup's MFMAs cover this latency
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(s[i]);
+            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
             lds_store_quad(mainT, col, row, v);
             if (save) g_store_quad(RHO + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
         });
