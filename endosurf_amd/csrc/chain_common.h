@@ -162,7 +162,7 @@ __device__ __forceinline__ void prefetch_quads(float (&buf)[RTC * NTC * 4][4], c
             for (int q = 0; q < 4; ++q) {
                 const float* p = base + (grow0 + (rt0 + ri) * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + ni) * 32 + lo;
                 float(&b)[4] = buf[(ri * NTC + ni) * 4 + q];
-                b[0] = p[0]; b[1] = p[ld]; b[2] = p[2 * ld]; b[3] = p[3 * ld];
+                b[0] = __builtin_nontemporal_load(p); b[1] = __builtin_nontemporal_load(p + ld); b[2] = __builtin_nontemporal_load(p + 2 * ld); b[3] = __builtin_nontemporal_load(p + 3 * ld);
             }
 }
 // The 8 quads (ri, q) of ONE n-tile column block ni of a 64 x 64 wave tile: batch index b8 = ri*4 + q.  Epilogues that read
@@ -177,7 +177,7 @@ __device__ __forceinline__ void prefetch_half(float (&buf)[8][4], const float* _
         for (int q = 0; q < 4; ++q) {
             const float* p = base + (grow0 + ri * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + NI) * 32 + lo;
             float(&b)[4] = buf[ri * 4 + q];
-            b[0] = p[0]; b[1] = p[ld]; b[2] = p[2 * ld]; b[3] = p[3 * ld];
+            b[0] = __builtin_nontemporal_load(p); b[1] = __builtin_nontemporal_load(p + ld); b[2] = __builtin_nontemporal_load(p + 2 * ld); b[3] = __builtin_nontemporal_load(p + 3 * ld);
         }
 }
 template <int NI, class F>
@@ -221,11 +221,14 @@ __device__ __forceinline__ void lds_add_quad(float* At, int col, int row, const 
 // rows row..row+3 of column col of a row-major [rows][ld] HBM buffer (each wave store = 2 x 128 B lines)
 __device__ __forceinline__ void g_store_quad(float* __restrict__ base, size_t grow0, int ld, int row, int col, const float (&v)[4]) {
     float* p = base + (grow0 + row) * (size_t)ld + col;
-    p[0] = v[0]; p[ld] = v[1]; p[2 * ld] = v[2]; p[3 * ld] = v[3];
+    // streamed once (read back by a later kernel): non-temporal, so the activation stream does not evict the weights from L2
+    __builtin_nontemporal_store(v[0], p); __builtin_nontemporal_store(v[1], p + ld);
+    __builtin_nontemporal_store(v[2], p + 2 * ld); __builtin_nontemporal_store(v[3], p + 3 * ld);
 }
 __device__ __forceinline__ void g_load_quad(const float* __restrict__ base, size_t grow0, int ld, int row, int col, float (&v)[4]) {
     const float* p = base + (grow0 + row) * (size_t)ld + col;
-    v[0] = p[0]; v[1] = p[ld]; v[2] = p[2 * ld]; v[3] = p[3 * ld];
+    v[0] = __builtin_nontemporal_load(p); v[1] = __builtin_nontemporal_load(p + ld);
+    v[2] = __builtin_nontemporal_load(p + 2 * ld); v[3] = __builtin_nontemporal_load(p + 3 * ld);
 }
 
 // Load a [64][NC] row-major HBM tile into rows 0..NC-1 of the k-major LDS tile (rows grow0.. of ``src``, leading dim ld).
