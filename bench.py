@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward", "frame"])
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
-    ap.add_argument("--schedule", default="fused", choices=["overlap", "fused", "split", "plain"])
+    ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
     args = ap.parse_args()
 
     from endosurf_amd import EndoSurfRenderer, parallel

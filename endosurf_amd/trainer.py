@@ -32,7 +32,7 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
 
 
 def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                       u_perturb=None, u_neigh=None, loss_kernel: bool = True, split_aux: bool = False):
+                       u_perturb=None, u_neigh=None, loss_kernel: bool = True):
     """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
     inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
     rays = renderer._rays32(batch["rays"])
@@ -55,62 +55,12 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     eod_pts = aux_x[:N]
     main.wait_stream(side)
     z.record_stream(main)
-    if split_aux:
-        # the 3N auxiliary points as their own (small) launches on the side stream, concurrent with the render's: they fill
-        # the slots the render's kernels free at the end of their last full round instead of adding a nearly empty round
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            a_sdf, a_go = renderer._point_eval(aux_x, aux_t)
-        ret = renderer(rays, iter_step=iter_step, z_vals=z)
-        main.wait_stream(side)
-        a_sdf.record_stream(main)
-        a_go.record_stream(main)
-    else:
-        ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
-        a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
+    ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
+    a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
     if loss_kernel:
         total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], ret["gradient_o_error"], a_sdf, a_go, renderer.engine, rays, eod_pts,
                                  color_gt, depth_gt, mask_gt, cmask, valid_sn, weights)
         return total, dict(color=t[0], depth=t[1], sdf=t[2], angle=t[3], eikonal=t[4], surf_neig=t[5]), ret
-    color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
-    sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
-    depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
-    eik = ret["gradient_o_error"]
-    sn = renderer._sn_loss(a_go[N:], valid_sn)
-    total = (color_loss * weights["color"] + depth_loss * weights["depth"] + sdf_loss * weights["sdf"]
-             + angle_loss * weights["angle"] + eik * weights["eikonal"] + weights["surf_neig"] * sn)
-    terms = dict(color=color_loss, depth=depth_loss, sdf=sdf_loss, angle=angle_loss, eikonal=eik, surf_neig=sn)
-    return total, terms, ret
-
-
-def compute_loss_split(renderer, batch, iter_step, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, u_perturb=None, u_neigh=None):
-    return compute_loss_fused(renderer, batch, iter_step, weights, surf_neig_rad, u_perturb, u_neigh, split_aux=True)
-
-
-def compute_loss_overlapped(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                            u_perturb=None, u_neigh=None):
-    """Same loss as compute_loss on two HIP streams: the main stream renders (sampling, fused point evaluation, compositing)
-    while a side stream runs the latency-bound chain ray marching -> 8 secant steps -> point evaluation of the 3N auxiliary
-    points (errorondepth + surface neighbours).  The small launches of either stream fill the tails of the other's large
-    ones, and autograd replays each branch's backward on the stream its forward ran on, so the backward overlaps too."""
-    rays = renderer._rays32(batch["rays"])
-    color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
-    N = rays.shape[0]
-    dev = rays.device
-    renderer._weights()          # weight-norm + packing once per step, with the autograd node, before the streams fork
-    main = torch.cuda.current_stream(dev)
-    side = getattr(renderer, "_side_stream", None)
-    if side is None:
-        side = renderer._side_stream = torch.cuda.Stream(device=dev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        eod_pts, time = renderer._eod_points(rays, depth_gt)
-        sn_pts, sn_t, valid_sn = renderer._sn_points(rays, mask_gt, surf_neig_rad, u_neigh)
-        a_sdf, a_go = renderer._point_eval(torch.cat([eod_pts, sn_pts], 0), torch.cat([time, sn_t], 0))
-    ret = renderer(rays, iter_step=iter_step, u_perturb=u_perturb)
-    main.wait_stream(side)
-    for t in (eod_pts, valid_sn, a_sdf, a_go):
-        t.record_stream(main)
     color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
     sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
     depth_loss = ((ret["depth_map"] - depth_gt) * valid * mask_gt).abs().sum() / ((valid * mask_gt).sum() + 1e-10)
@@ -295,9 +245,9 @@ class Trainer:
         self.lr_init, self.n_iter, self.warm_up_end, self.lr_alpha = lr, n_iter, warm_up_end, lr_alpha
         self.loss_weights, self.surf_neig_rad = loss_weights, surf_neig_rad
         self.data_parallel = data_parallel
-        # "overlap": two-stream schedule; "fused": auxiliary points inside the render launches; "plain": reference call sequence
+        # "fused": auxiliary points inside the render launches (default); "plain": the reference's call sequence
         schedule = schedule or ("fused" if fused else "plain")
-        self.loss_fn = {"overlap": compute_loss_overlapped, "fused": compute_loss_fused, "split": compute_loss_split, "plain": compute_loss}[schedule]
+        self.loss_fn = {"fused": compute_loss_fused, "plain": compute_loss}[schedule]
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)

@@ -156,8 +156,8 @@ def test_training_loss_param_grads(name):
 
 @pytest.mark.parametrize("name", ["trained_deform", "trained_nodeform"])
 def test_fused_training_loss_matches_unfused(name):
-    """compute_loss_fused (aux points inside the render launches) == compute_loss (three separate evaluations)."""
-    from endosurf_amd.trainer import compute_loss, compute_loss_fused, compute_loss_overlapped, compute_loss_split
+    """compute_loss_fused (aux points inside the render launches, fused loss kernel) == compute_loss (reference call sequence)."""
+    from endosurf_amd.trainer import compute_loss, compute_loss_fused
     c = load_case(name)
     dev = "cuda"
     batch = dict(rays=torch.from_numpy(c["rays"]).to(dev), color=torch.from_numpy(c["target/color"]).to(dev),
@@ -166,7 +166,7 @@ def test_fused_training_loss_matches_unfused(name):
     u = torch.from_numpy(c["u_perturb"]).to(dev) if "u_perturb" in c else None
     un = torch.from_numpy(c["u_neigh"]).to(dev)
     res = []
-    for fn in (compute_loss, compute_loss_fused, compute_loss_overlapped, compute_loss_split):
+    for fn in (compute_loss, compute_loss_fused):
         r = renderer_for_case(c)
         r.perturb = u is not None
         total, terms, _ = fn(r, batch, int(c["meta/iter_step"]), u_perturb=u, u_neigh=un)
