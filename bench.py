@@ -99,8 +99,8 @@ def pmc_traffic(kernel_desc):
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
     if not files:
         return None
-    kname = kernel_desc.split(" ")[0].split("[")[0]
-    rows = [r for r in json.load(open(files[-1])) if r.get("logical", r["kernel"].split("<")[0]) == kname]
+    kname = kernel_desc.split(" ")[0]
+    rows = [r for r in json.load(open(files[-1])) if r.get("logical", r["kernel"].split("<")[0]) in (kname, kname.split("[")[0])]
     if not rows:
         return None
     r = max(rows, key=lambda r: r["cycles"] * r["launches"])
