@@ -95,3 +95,35 @@ def test_flat_adam_gathers_accumulated_gradients():
     assert r.model._epoch == 1 and not torch.equal(before, r.model._flat)
     opt.zero_grad()
     assert all(p.grad is None for p in r.parameters())
+
+
+def test_flat_adam_state_roundtrip_and_checkpoint():
+    """Checkpoint resume: renderer.save_checkpoint() + FlatAdam.state_dict() restored into fresh objects continue identically
+    (same parameters after the next update when fed the same gradient)."""
+    from endosurf_amd.trainer import FlatAdam
+    c = load_case("trained_deform")
+    rays = torch.from_numpy(c["rays"]).cuda()
+
+    def grad_step(r, opt):
+        opt.zero_grad()
+        r(rays, iter_step=1, perturb_overwrite=False)["color_map"].sum().backward()
+        return opt.flat_grad(include_variance=True).clone()
+
+    r1 = renderer_for_case(c)
+    o1 = FlatAdam(r1, lr=1e-3)
+    g = grad_step(r1, o1)
+    o1.step(grad=g, variance_in_grad=True)
+    ckpt, sd = r1.save_checkpoint(), o1.state_dict()
+    r2 = renderer_for_case(c)
+    r2.load_checkpoint(ckpt)
+    o2 = FlatAdam(r2, lr=123.0)
+    o2.load_state_dict(sd)
+    assert torch.equal(r1.model._flat, r2.model._flat) and o2.step_count == 1 and o2.param_groups[0]["lr"] == 1e-3
+    g2 = torch.randn_like(g)
+    o1.step(grad=g2, variance_in_grad=True)
+    o2.step(grad=g2, variance_in_grad=True)
+    assert torch.equal(r1.model._flat, r2.model._flat)
+    with torch.no_grad():       # the restored renderer renders with the restored weights (packed-weight cache invalidated)
+        a = r1(rays, iter_step=1, perturb_overwrite=False)["color_map"]
+        b = r2(rays, iter_step=1, perturb_overwrite=False)["color_map"]
+    assert torch.equal(a, b)
