@@ -56,7 +56,7 @@ __device__ __forceinline__ void epi16(f32x4v (&acc)[4], float* mainT, int nt0, i
     for (int ni = 0; ni < 4; ++ni) {
         const int col = (nt0 + ni) * 16 + lo;
         float v[4] = {acc[ni][0], acc[ni][1], acc[ni][2], acc[ni][3]};
-        f(col, rb, v);
+        f(col, rb, v, ni);
         *reinterpret_cast<float4*>(&mainT[swz16(col, rb)]) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
@@ -121,9 +121,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
     }
     for (int i = tid; i < Q16_AUX; i += NTHREADS) aux[i] = 0.f;          // zero padding rows (k up to 64)
     __syncthreads();
-    auto relu_epi = [&](f32x4v(&acc)[4], const float* bias) {
-        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
-            const float b = bias[col];
+    // biases are fetched BEFORE the layer's GEMM: an L2 round trip in the epilogue would sit on the critical path of every layer
+    auto load_bias = [&](float(&bq)[4], const float* bias) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bq[ni] = bias[(nt0 + ni) * 16 + (lane & 15)];
+    };
+    auto relu_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
+        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
+            const float b = bq[ni];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
         });
@@ -148,23 +153,26 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
         {
             f32x4v acc[4];
             zero4(acc);
+            float bq[4];
+            load_bias(bq, weff + tb.boff[NET_D * LAYERS + 0]);
             gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane);
-            relu_epi(acc, weff + tb.boff[NET_D * LAYERS + 0]);
+            relu_epi(acc, bq);
         }
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             f32x4v acc[4];
             zero4(acc);
+            float bq[4];
+            load_bias(bq, weff + tb.boff[NET_D * LAYERS + l]);
             gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane);
             __syncthreads();
-            const float* bias = weff + tb.boff[NET_D * LAYERS + l];
-            epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
+            epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
                 if (l == 3 && col >= 204) {                                  // IDR skip: [h(204) | enc(52)]
                     const float4 e = *reinterpret_cast<const float4*>(&aux[swz16(col - 204, rb)]);
                     v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
                 } else {
-                    const float b = bias[col];
+                    const float b = bq[ni];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
                 }
@@ -183,9 +191,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
     }
     encode3_16<6>(aux, 0, px, tid);
     __syncthreads();
-    auto sp_epi = [&](f32x4v(&acc)[4], const float* bias) {
-        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4]) {
-            const float b = bias[col];
+    auto sp_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
+        epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
+            const float b = bq[ni];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
         });
@@ -193,8 +201,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
     {
         f32x4v acc[4];
         zero4(acc);
+        float bq[4];
+        load_bias(bq, weff + tb.boff[NET_S * LAYERS + 0]);
         gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane);
-        sp_epi(acc, weff + tb.boff[NET_S * LAYERS + 0]);
+        sp_epi(acc, bq);
     }
     __syncthreads();
 #pragma unroll 1
@@ -202,10 +212,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
         f32x4v acc[4];
         zero4(acc);
         const int pi = l <= 4 ? 8 + l : 8 + l + 1;          // P16_SEGS order: SF0..SF3, SF4M, SF4A, SF5..SF7
+        float bq[4];
+        load_bias(bq, weff + tb.boff[NET_S * LAYERS + l]);
         gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane);
         if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane);
         __syncthreads();
-        sp_epi(acc, weff + tb.boff[NET_S * LAYERS + l]);
+        sp_epi(acc, bq);
         __syncthreads();
     }
     smalln16<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);

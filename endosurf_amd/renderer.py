@@ -247,6 +247,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int, aux_x, aux_t):
         N, S = z.shape
         P_ = N * S
+        ctx.set_materialize_grads(False)          # unused outputs (weights, cdf, ...) arrive as None, not as zero-filled tensors
         mid = eng.mid_z(z, sample_dist)
         fused = aux_x is not None and aux_x.shape[0] > 0 and P_ % 64 == 0
         pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=aux_x if fused else None, t=aux_t if fused else None)

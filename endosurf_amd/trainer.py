@@ -96,6 +96,7 @@ class _LossFn(torch.autograd.Function):
         for name, t in zip(("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go"), [terms] + grads):
             setattr(a, name, _lib.ptr(t))
         _lib.check(eng.lib.es_train_loss(C.byref(a), _lib.stream_ptr()), "es_train_loss")
+        ctx.set_materialize_grads(False)
         ctx.grads = grads
         ctx.eik_shape = eik.shape
         ctx.mark_non_differentiable(terms)
@@ -103,6 +104,8 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
+        if g_total is None:
+            return (None,) * 14
         gc, gd, ge, gs, gg = torch._foreach_mul(ctx.grads, g_total)       # one multi-tensor launch
         return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None)
 

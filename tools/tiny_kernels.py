@@ -6,7 +6,8 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if "k_weff" in r[2]]
-a, b = starts[-4], starts[-3]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+a, b = starts[-k - 1], starts[-k]
 t0 = rows[a][0]
 import re
 for s, e, n in rows[a:b]:
