@@ -3,7 +3,8 @@
 // All problems of one network are batched in ONE launch (grouped GEMM): independent workgroup tasks (problem, 256 x 128
 // tile of dW, row chunk) whose operand panels are staged through LDS, contraction on v_mfma_f32_32x32x2_f32, results reduced
 // with fp32 atomics (few row chunks per output tile).  Bias gradients are column sums of dA taken on the fly by the
-// k-block-0 tasks.
+// k-block-0 tasks.  The last layers' tiny-N gradients (3 / 1 outputs: an HBM stream over the layer input) are sliced over
+// the GEMM tasks of the same launch.
 #include <hip/hip_runtime.h>
 
 #include "arch.h"
@@ -21,9 +22,18 @@ struct WgProb {
     const float* X; const float* dA; float* out; float* bias_out;
     int ldx, lda, ldo, M, K, N, bias_stride, task_begin;
 };
+// tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k] — a latency-bound HBM stream over X (dA == nullptr means
+// dA = 1: column sums of X).  Every GEMM task of the network's launch streams a slice of it, half of the tasks before and
+// half after their GEMM, so that the two workgroups of a CU are out of phase and the matrix pipes stay busy meanwhile.
+struct WgSmall {
+    const float* X; const float* dA; float* out; float* bias_out;
+    int ldx, lda, ldo, M, K, N, bias_stride;
+};
+constexpr int WG_MAX_SMALL = 2;
 struct WgArgs {
     WgProb p[WG_MAX_PROBS];
-    int nprob, total_tasks, MC;
+    WgSmall s[WG_MAX_SMALL];
+    int nprob, total_tasks, MC, nsmall;
 };
 
 // One workgroup (8 waves) = one task: a [256 x 128] tile of dW (all 256 output features x 128 input features) over a chunk
@@ -139,11 +149,79 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     }
 }
 
+// Slice `slot` of `nslots` of a small problem: thread = (input feature k, row-block parity); 16-row blocks, the loads of two
+// steps (2 x 16 rows of X per thread) in flight, the <= 4 adjoint columns go through LDS (double buffered, one barrier per step).
+constexpr int WS_ROWS = 16;
+__device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int nslots, float* lds) {
+    float(*sd)[WS_ROWS][4] = reinterpret_cast<float(*)[WS_ROWS][4]>(lds);       // [half * 2 + buffer]
+    const int tid = threadIdx.x, k = tid & 255, half = tid >> 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int nblk = (P.M + WS_ROWS - 1) / WS_ROWS;
+    const int step = 2 * nslots;
+    // X rows up to the next multiple of 64 exist (finite padding rows of the workspace; their adjoints are read as 0)
+    auto loadx = [&](float(&x)[WS_ROWS], int b0) {
+        const int m0 = b0 + half < nblk ? (b0 + half) * WS_ROWS : 0;
+        const float* xp = P.X + (size_t)m0 * P.ldx + k;
+#pragma unroll
+        for (int r = 0; r < WS_ROWS; ++r) x[r] = __builtin_nontemporal_load(xp + (size_t)r * P.ldx);
+    };
+    auto consume = [&](const float(&x)[WS_ROWS], int b0, int it) {
+        const bool live = b0 + half < nblk;                                     // half-uniform
+        const int m0 = live ? (b0 + half) * WS_ROWS : 0;
+        float(&sdb)[WS_ROWS][4] = sd[half * 2 + (it & 1)];
+        if (k < WS_ROWS * 4) {
+            const int r = k >> 2, n = k & 3;
+            sdb[r][n] = (live && m0 + r < P.M && n < P.N) ? (P.dA ? P.dA[(size_t)(m0 + r) * P.lda + n] : 1.f) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WS_ROWS; ++r)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = fmaf(sdb[r][n], x[r], acc[n]);
+        if (P.bias_out && k < P.N)
+            for (int r = 0; r < WS_ROWS; ++r)
+                if (((m0 + r) % P.bias_stride) == 0) bsum += sdb[r][k];
+    };
+    float xa[WS_ROWS], xb[WS_ROWS];
+    int b0 = 2 * slot, it = 0;
+    if (b0 < nblk) loadx(xa, b0);
+#pragma unroll 1
+    while (b0 < nblk) {
+        if (b0 + step < nblk) loadx(xb, b0 + step);
+        consume(xa, b0, it++);
+        b0 += step;
+        if (b0 >= nblk) break;
+        if (b0 + step < nblk) loadx(xa, b0 + step);
+        consume(xb, b0, it++);
+        b0 += step;
+    }
+    // the two row-block parities are summed through LDS: one atomic per (output, k) and task
+    __syncthreads();
+    float* red = lds;
+    if (half) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) red[n * 256 + k] = acc[n];
+        red[1024 + k] = bsum;
+    }
+    __syncthreads();
+    if (!half) {
+        for (int n = 0; n < P.N; ++n) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[n] + red[n * 256 + k]);
+        if (P.bias_out && k < P.N) atomicAdd(P.bias_out + k, bsum + red[1024 + k]);
+    }
+    __syncthreads();
+}
+
 // NET only names the instantiation (0 deform, 1 sdf, 2 colour) so that profilers list the three grouped launches separately
 template <int NET>
 __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int task = blockIdx.x;
+    // blocks b and b + (tasks of the round)/2 tend to share a CU: one of them streams its small slices first, the other last
+    const bool small_first = task < a.total_tasks / 2;
+    if (small_first)
+#pragma unroll 1
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task(a.s[i], task, a.total_tasks, wlds);
     int pi = 0;
 #pragma unroll 1
     for (int i = 1; i < a.nprob; ++i)
@@ -163,49 +241,16 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     } else { kb = local % kblk; mc = local / kblk; }
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
     wgrad_task(P, kb, m0, m1, wlds);
-}
-
-// tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k], one thread per k (K <= 256), 32 rows per block:
-// the adjoint rows go through LDS once, then all 32 row loads of X are in flight together (pure HBM stream over X).
-// dA == nullptr means dA = 1 (column sums of X).
-constexpr int WS_ROWS = 32;       // rows per inner step (all loads in flight together)
-constexpr int WS_STEPS = 4;       // steps per block (128 rows): enough blocks to keep every CU streaming
-__global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ X, int ldx, const float* __restrict__ dA, int lda, int M, int K,
-                                                     int N, float* __restrict__ out, int ldo, float* __restrict__ bias_out, int bias_stride) {
-    __shared__ float sd[2][WS_ROWS][4];
-    const int k = threadIdx.x;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    const int mbase = blockIdx.x * (WS_ROWS * WS_STEPS);
+    if (!small_first) {
+        __syncthreads();
 #pragma unroll 1
-    for (int it = 0; it < WS_STEPS; ++it) {
-        const int m0 = mbase + it * WS_ROWS;
-        if (m0 >= M) break;
-        float(&sdb)[WS_ROWS][4] = sd[it & 1];
-        if (k < WS_ROWS * 4) {
-            const int r = k >> 2, n = k & 3;
-            sdb[r][n] = (m0 + r < M && n < N) ? (dA ? dA[(size_t)(m0 + r) * lda + n] : 1.f) : 0.f;
-        }
-        float x[WS_ROWS];
-#pragma unroll
-        for (int r = 0; r < WS_ROWS; ++r) x[r] = (k < K && m0 + r < M) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
-        __syncthreads();                                   // double-buffered sd: one barrier per step suffices
-#pragma unroll
-        for (int r = 0; r < WS_ROWS; ++r)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = fmaf(sdb[r][n], x[r], acc[n]);
-        if (bias_out && k < N)
-            for (int r = 0; r < WS_ROWS; ++r)
-                if (((m0 + r) % bias_stride) == 0) bsum += sdb[r][k];
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task(a.s[i], task, a.total_tasks, wlds);
     }
-    if (k < K)
-        for (int n = 0; n < N; ++n) atomicAdd(out + (size_t)n * ldo + k, acc[n]);
-    if (bias_out && k < N) atomicAdd(bias_out + k, bsum);
 }
 
 static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
 
-static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipStream_t st) {
+static int launch_group(WgProb* probs, int nprob, const WgSmall* small, int nsmall, int kid, long long rows, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         if (int e = allow_big_lds(k_wgrad<0>, WG_LDS_FLOATS * 4)) return e;
@@ -223,6 +268,7 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
         for (int i = 0; i < nprob; ++i) t += (long long)wg_kblk(probs[i]) * ((probs[i].M + mc - 1) / mc);
         return t;
     };
+    ES_REQUIRE(nsmall <= WG_MAX_SMALL, "too many small weight-gradient problems in one group");
     int MC = 128;
     while (MC < 65536 && count(MC) > 512) MC += 64;
     WgArgs a;
@@ -234,19 +280,18 @@ static int launch_group(WgProb* probs, int nprob, int kid, long long rows, hipSt
         total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
         a.p[i] = probs[i];
     }
-    a.nprob = nprob; a.total_tasks = total; a.MC = MC;
+    a.nprob = nprob; a.total_tasks = total; a.MC = MC; a.nsmall = nsmall;
+    for (int i = 0; i < nsmall; ++i) {
+        ES_REQUIRE(small[i].K == 256 && small[i].N <= 4, "small weight-gradient problems are [<=4 x 256]");
+        a.s[i] = small[i];
+    }
+    const dim3 grid(total);
     ScopedTimer tm(kid, rows, st);
-    if (kid == KID_WGRAD_D) hipLaunchKernelGGL(k_wgrad<0>, dim3(total), dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
-    else if (kid == KID_WGRAD_S) hipLaunchKernelGGL(k_wgrad<1>, dim3(total), dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
-    else hipLaunchKernelGGL(k_wgrad<2>, dim3(total), dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    if (kid == KID_WGRAD_D) hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    else if (kid == KID_WGRAD_S) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    else hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
     return ST_OK;
 }
-static void launch_small(const float* X, int ldx, const float* dA, int lda, int M, int K, int N, float* out, int ldo, float* bias_out,
-                         int bias_stride, hipStream_t st) {
-    ScopedTimer tm(KID_WGRAD_SMALL, M, st);
-    hipLaunchKernelGGL(k_wgrad_small, dim3((M + WS_ROWS * WS_STEPS - 1) / (WS_ROWS * WS_STEPS)), dim3(256), 0, st, X, ldx, dA, lda, M, K, N, out, ldo, bias_out, bias_stride);
-}
-
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st) {
     if (M <= 0) return ST_OK;
@@ -259,7 +304,11 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
     auto dW = [&](int net, int l) { return dweff + tb.woff[net * LAYERS + l]; };
     auto dB = [&](int net, int l) { return dweff + tb.boff[net * LAYERS + l]; };
     WgProb g[WG_MAX_PROBS];
-    int n = 0;
+    WgSmall sm[WG_MAX_SMALL];
+    int n = 0, ns = 0;
+    auto small = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride) {
+        sm[ns++] = WgSmall{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride};
+    };
     auto add = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride) {
         g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0};
     };
@@ -277,9 +326,10 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             add(B(WS_D_T) + (size_t)(l - 1) * t256, 256, B(WS_D_R) + (size_t)l * t256, 256, Mp, 256, LAYER_N[NET_D][l], dW(NET_D, l), 256,
                 nullptr, 1);
         }
-        if (int e = launch_group(g, n, KID_WGRAD_D, M, st)) return e;
-        launch_small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2, st);
-        launch_small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1, st);
+        ns = 0;     // last layer (3 outputs)
+        small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2);
+        small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
+        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_D, M, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l)
         n = 0;
@@ -296,10 +346,11 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         }
         if (flags & PF_COLOR)   // feature rows 1..256 of the last layer
             add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
-        if (int e = launch_group(g, n, KID_WGRAD_S, M, st)) return e;
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
-        launch_small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, st);   // real rows only: d_sdf is [M]
-        launch_small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, st);
+        ns = 0;
+        small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1);   // real rows only: d_sdf is [M]
+        small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1);
+        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, st)) return e;
     }
     if (flags & PF_COLOR) {
         n = 0;
@@ -313,8 +364,9 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
                 add(B(WS_FEAT), 256, B(WS_C_Y) + (size_t)4 * t256, 256, Mc, 256, 256, dW(NET_C, 4) + 349, K, nullptr, 1);
             }
         }
-        if (int e = launch_group(g, n, KID_WGRAD_C, Mc, st)) return e;
-        launch_small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1, st);
+        ns = 0;
+        small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1);
+        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_C, Mc, st)) return e;
     }
     return hip_last("point_wgrad");
 }
