@@ -23,13 +23,13 @@ struct WgProb {
     int ldx, lda, ldo, M, K, N, bias_stride, task_begin;
 };
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k] — a latency-bound HBM stream over X (dA == nullptr means
-// dA = 1: column sums of X).  Every GEMM task of the network's launch streams a slice of it, half of the tasks before and
+// dA = 1: column sums of X).  Every GEMM task of the hosting launch streams a slice of it, half of the tasks before and
 // half after their GEMM, so that the two workgroups of a CU are out of phase and the matrix pipes stay busy meanwhile.
 struct WgSmall {
     const float* X; const float* dA; float* out; float* bias_out;
     int ldx, lda, ldo, M, K, N, bias_stride;
 };
-constexpr int WG_MAX_SMALL = 2;
+constexpr int WG_MAX_SMALL = 4;
 struct WgArgs {
     WgProb p[WG_MAX_PROBS];
     WgSmall s[WG_MAX_SMALL];
@@ -326,10 +326,8 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             add(B(WS_D_T) + (size_t)(l - 1) * t256, 256, B(WS_D_R) + (size_t)l * t256, 256, Mp, 256, LAYER_N[NET_D][l], dW(NET_D, l), 256,
                 nullptr, 1);
         }
-        ns = 0;     // last layer (3 outputs)
-        small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, R, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2);
-        small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
-        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_D, M, st)) return e;
+        // the deformation launch (the longest) stays a pure GEMM: its last layer's slices ride with the two shorter launches
+        if (int e = launch_group(g, n, sm, 0, KID_WGRAD_D, M, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l)
         n = 0;
@@ -348,6 +346,11 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
         ns = 0;
+        if (flags & PF_DEFORM) {     // last deformation layer (3 outputs): value + J d rows here, (tau_8, g_c) pair with the colour launch
+            const size_t r256 = (size_t)2 * Mp * 256;
+            small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, 2 * Mp, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2);
+            if (!(flags & PF_COLOR)) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
+        }
         small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1);   // real rows only: d_sdf is [M]
         small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1);
         if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, st)) return e;
@@ -365,6 +368,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             }
         }
         ns = 0;
+        if (flags & PF_DEFORM) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
         small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1);
         if (int e = launch_group(g, n, sm, ns, KID_WGRAD_C, Mc, st)) return e;
     }
