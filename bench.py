@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "forward", "frame"])
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
+    ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
     from endosurf_amd import EndoSurfRenderer, parallel
@@ -179,7 +180,7 @@ def main():
 
     def step(i):
         if args.mode == "frame":
-            renderer.render_frames(frame_rays, iter_step=1, ray_chunk=2048, perturb_overwrite=False, use_graph=not args.no_graph)
+            renderer.render_frames(frame_rays, iter_step=1, ray_chunk=args.chunk, perturb_overwrite=False, use_graph=not args.no_graph)
         elif args.mode == "train":
             trainer.update_learning_rate(i + 1)
             trainer.train_step(batches[i % len(batches)], i + 1)
@@ -241,13 +242,13 @@ def main():
                         traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=tr[1] if tr else None, kernel=name,
                         avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
         out = dict(metric={"train": "training rays/sec (1024 rays x 64 samples)", "forward": "forward rays/sec (1024 rays x 64 samples)",
-                           "frame": "full-frame render rays/sec (640x512, 64 samples, 2048-ray chunks)"}[args.mode],
+                           "frame": "full-frame render rays/sec (640x512, 64 samples, %d-ray chunks)" % args.chunk}[args.mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                    scaling="strong" if args.mode == "frame" else "weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="base_pull.yml nets, %d rays x (32+32) samples per GPU, %s" % (
                        args.rays, "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam"
                        if args.mode == "train" else ("renderer forward only" if args.mode == "forward" else
-                                                     "one 640x512 frame per step, forward only, hipGraph-captured 2048-ray chunks" + (" (eager)" if args.no_graph else ""))),
+                                                     "one 640x512 frame per step, forward only, hipGraph-captured %d-ray chunks" % args.chunk + (" (eager)" if args.no_graph else ""))),
                        ray_marching=("128 proposals per ray in blocks of %d with early exit at each ray's first sign change (results identical "
                                      "to evaluating all proposals; the synthetic init-weight scene resolves every ray in the first block)" % eng.march_block
                                      if eng.march_block else "all 128 proposals per ray"),
