@@ -72,6 +72,7 @@ PROTOTYPES = {
     "es_train_loss": (_I, [C.POINTER(es_loss_args), _P]),
     "es_query_sdf_rays": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _I, _P]),
     "es_march_progress": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
+    "es_variance_terms": (_I, [_P, _P, _P, _P, _P]),
     "es_train_aux_points": (_I, [_P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P]),
     "es_adam_step": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_longlong, _P]),
     "es_timing_enable": (_I, [_I]),

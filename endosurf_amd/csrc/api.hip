@@ -14,6 +14,7 @@ int weightnorm_backward(const float* params, const float* dweff, float* dparams,
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out = 0, const int* ray_done = nullptr);
 int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st);
+int variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, hipStream_t st);
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
@@ -125,6 +126,10 @@ int es_query_sdf_rays(const es_points* pts, const float* packed, const float* we
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
     ES_REQUIRE(pts->mode == 1 && pts->n_per_ray >= 1 && ld_out >= pts->n_per_ray, "es_query_sdf_rays takes ray samples (mode 1), ld_out >= n_per_ray");
     return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream, ld_out, ray_done);
+}
+int es_variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, void* stream) {
+    ES_REQUIRE(variance && (s_val || d_var) && (!d_var || d_invs_acc), "es_variance_terms arguments");
+    return variance_terms(variance, d_invs_acc, s_val, d_var, (hipStream_t)stream);
 }
 int es_march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, void* stream) {
     ES_REQUIRE(sdf && done && n >= 2 && n_valid >= 1 && n_valid <= n, "es_march_progress arguments");

@@ -510,6 +510,20 @@ int march_find(const float* sdf, const float* dprop, int N, int n, float tau, fl
     hipLaunchKernelGGL(k_march_find, ray_grid(N), dim3(256), 0, st, sdf, dprop, N, n, tau, state, flags, d_pred);
     return hip_last("march_find");
 }
+// scalar epilogue of the deviation network (endosurf.py:168, :205, :845-852): s_val = 1 / inv_s and the chain rule
+// d var = d inv_s * 10 exp(10 var) inside the clip range (0 outside)
+__global__ void k_variance_terms(const float* __restrict__ variance, const float* __restrict__ d_invs_acc, float* __restrict__ s_val,
+                                 float* __restrict__ d_var) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float e = expf(variance[0] * 10.f);
+    if (s_val) s_val[0] = 1.f / fminf(fmaxf(e, 1e-6f), 1e6f);
+    if (d_var) d_var[0] = (e >= 1e-6f && e <= 1e6f) ? d_invs_acc[0] * 10.f * e : 0.f;
+}
+int variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, hipStream_t st) {
+    hipLaunchKernelGGL(k_variance_terms, dim3(1), dim3(64), 0, st, variance, d_invs_acc, s_val, d_var);
+    return hip_last("variance_terms");
+}
+
 int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st) {
     if (N <= 0) return ST_OK;
     hipLaunchKernelGGL(k_march_progress, ray_grid(N), dim3(256), 0, st, sdf, N, n, n_valid, tau, done);

@@ -178,6 +178,16 @@ class Engine:
         return out
 
     # ---- ray marching ------------------------------------------------------------------------------
+    def variance_terms(self, variance, d_invs_acc=None):
+        """SingleVarianceNetwork's scalar epilogue: s_val = 1 / inv_s, or (with ``d_invs_acc``) the gradient of the variance."""
+        out = self.empty(1)
+        v = _f32(variance).reshape(1)
+        if d_invs_acc is None:
+            check(self.lib.es_variance_terms(ptr(v), None, ptr(out), None, stream_ptr()), "es_variance_terms")
+        else:
+            check(self.lib.es_variance_terms(ptr(v), ptr(d_invs_acc), None, ptr(out), stream_ptr()), "es_variance_terms")
+        return out
+
     def march_begin(self, rays, weff, packed, use_deform, n_steps=128, tau=0.0):
         """First half of ray_marching (reference endosurf.py:352-406): SDF at n_steps proposals per ray (one big launch) and the
         first sign change -> secant bracket. Returns the state consumed by march_refine."""

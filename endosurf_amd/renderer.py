@@ -215,6 +215,23 @@ class _PackFn(torch.autograd.Function):
         return (None, None, *[dflat[off:off + n].view(shape) for off, n, shape in ctx.slots])
 
 
+class _SValFn(torch.autograd.Function):
+    """s_val = 1 / clip(exp(10 variance), 1e-6, 1e6) (endosurf.py:168, :205) in one launch; differentiable like the reference's."""
+
+    @staticmethod
+    def forward(ctx, variance, eng: Engine):
+        s = eng.variance_terms(variance.detach())
+        ctx.save_for_backward(s)
+        ctx.shape = variance.shape
+        return s.reshape(variance.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        s, = ctx.saved_tensors
+        inside = ((s > 1e-6) & (s < 1e6)).to(s.dtype)          # d/dvar exp(-10 var) = -10 s_val inside the clip range
+        return (g.reshape(1) * -10.0 * s * inside).reshape(ctx.shape), None
+
+
 class _PointEvalFn(torch.autograd.Function):
     """Fused per-point evaluation (sdf, g_o[, rgb]) with hand-written backward to the effective weights."""
 
@@ -289,10 +306,8 @@ class _RenderFn(torch.autograd.Function):
             d_sdf = torch.cat([d_sdf, z(g_aux_sdf, ctx.n_aux, 1)], 0)
             d_go = torch.cat([d_go, z(g_aux_go, ctx.n_aux, 3)], 0)
         dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"])
-        # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852)
-        e = torch.exp(var * 10.0)
-        inside = ((e >= 1e-6) & (e <= 1e6)).to(e.dtype)
-        dvar = (bw["d_invs_acc"][0] * 10.0 * e * inside).reshape(ctx.variance.shape)
+        # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852): d var = d inv_s * 10 exp(10 var) inside the clip range
+        dvar = eng.variance_terms(var, d_invs_acc=bw["d_invs_acc"]).reshape(ctx.variance.shape)
         ctx.pctx = None                                           # release the workspace as soon as it has been consumed
         return dweff, None, dvar, None, None, None, None, None, None, None, None
 
@@ -428,7 +443,7 @@ class EndoSurfRenderer(nn.Module):
             weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), self._flags(weff), aux_x, aux_t)
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
-        s_val = torch.exp(var * -10.0).clip(1e-6, 1e6)          # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
+        s_val = _SValFn.apply(var, self.engine)                 # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
         return {"color_map": color, "depth_map": depth, "gradients_o": g_o, "gradient_o_error": eik, "cdf": cdf,
                 "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
 

@@ -128,3 +128,20 @@ def test_composite_forward_backward(name):
     # adj of inv_s -> variance: d inv_s / d var = 10 * inv_s (inside the clip)
     dvar = bw["d_invs_acc"].item() * 10.0 * float(inv_s)
     assert abs(dvar - float(var.grad)) < 2e-4 * abs(float(var.grad)) + 1e-6
+
+
+@pytest.mark.parametrize("var", [0.3, -0.2, 1.5, -1.45])
+def test_variance_terms_match_autograd(var):
+    """es_variance_terms: s_val = 1 / clip(exp(10 var), 1e-6, 1e6) and the clipped chain rule (endosurf.py:168, :205, :845-852)."""
+    import torch
+    from endosurf_amd.engine import Engine
+    eng = Engine(torch.device("cuda", 0))
+    v = torch.tensor([var], dtype=torch.float64, requires_grad=True)
+    inv_s = torch.exp(v * 10.0).clip(1e-6, 1e6)
+    g = 0.37
+    (inv_s * g).sum().backward()
+    vd = torch.tensor([var], device="cuda")
+    s_val = eng.variance_terms(vd)
+    dvar = eng.variance_terms(vd, d_invs_acc=torch.tensor([g], device="cuda"))
+    assert abs(s_val.item() - 1.0 / inv_s.item()) <= 2e-6 * (1.0 / inv_s.item())
+    assert abs(dvar.item() - v.grad.item()) <= 2e-6 * max(abs(v.grad.item()), 1e-30)
