@@ -231,6 +231,45 @@ __device__ __forceinline__ void g_load_quad(const float* __restrict__ base, size
     v[2] = __builtin_nontemporal_load(p + 2 * ld); v[3] = __builtin_nontemporal_load(p + 3 * ld);
 }
 
+// ---- fragment-ordered activation stacks --------------------------------------------------------------------------------
+// A [64 rows][256 columns] tile of a saved activation stack stored in accumulator-fragment order: the quad (4 consecutive rows
+// of one column) that a lane holds after the MFMA is ONE float4, and the 64 lanes of a wave access 1 KiB contiguously
+// (index ((wave * 16 + (ri * 2 + ni) * 4 + q) * 64 + lane) * 4, rows 32 ri + 8 q + 4 hi .., column 64 wave + 32 ni + lo).
+typedef float v4f_frag __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ size_t frag_off(size_t grow0, int row, int col) {
+    const int ri = row >> 5, q = (row >> 3) & 3, hi = (row >> 2) & 1;
+    const int w = col >> 6, ni = (col >> 5) & 1, lo = col & 31;
+    return grow0 * 256 + (size_t)(((w * 16 + (ri * 2 + ni) * 4 + q) * 64 + hi * 32 + lo) * 4);
+}
+__device__ __forceinline__ void g_store_quad_f(float* __restrict__ base, size_t grow0, int row, int col, const float (&v)[4]) {
+    const v4f_frag t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_frag*>(base + frag_off(grow0, row, col)));
+}
+__device__ __forceinline__ void g_load_quad_f(const float* __restrict__ base, size_t grow0, int row, int col, float (&v)[4]) {
+    const v4f_frag t = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(base + frag_off(grow0, row, col)));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <int RTC, int NTC>
+__device__ __forceinline__ void prefetch_quads_f(float (&buf)[RTC * NTC * 4][4], const float* __restrict__ base, size_t grow0, int rt0, int nt0,
+                                                 int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                g_load_quad_f(base, grow0, (rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, buf[(ri * NTC + ni) * 4 + q]);
+}
+template <int NI>
+__device__ __forceinline__ void prefetch_half_f(float (&buf)[8][4], const float* __restrict__ base, size_t grow0, int nt0, int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g_load_quad_f(base, grow0, ri * 32 + 8 * q + 4 * hi, (nt0 + NI) * 32 + lo, buf[ri * 4 + q]);
+}
+
 // Load a [64][NC] row-major HBM tile into rows 0..NC-1 of the k-major LDS tile (rows grow0.. of ``src``, leading dim ld).
 template <int NC>
 __device__ __forceinline__ void load_tile(float* At, const float* __restrict__ src, size_t grow0, int ld, int tid) {

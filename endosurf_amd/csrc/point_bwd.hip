@@ -283,8 +283,8 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     auto epi_t = [&](f32x16(&acc)[2][2], int l) {   // acc = pi_l
         auto half = [&](auto NI) {
             float S[8][4], Rr[8][4];
-            prefetch_half<decltype(NI)::value>(S, SACT + (size_t)l * Mp * 256, grow0, 256, 2 * wave, lane);
-            prefetch_half<decltype(NI)::value>(Rr, RHO + (size_t)l * Mp * 256, grow0, 256, 2 * wave, lane);
+            prefetch_half_f<decltype(NI)::value>(S, SACT + (size_t)l * Mp * 256, grow0, 2 * wave, lane);
+            prefetch_half_f<decltype(NI)::value>(Rr, RHO + (size_t)l * Mp * 256, grow0, 2 * wave, lane);
             for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
                 float z2[4];
 #pragma unroll
@@ -294,8 +294,8 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
                     v[i] = dphi * v[i];                                     // tau_{l+1}
                 }
                 lds_store_quad(mainT, col, row, v);
-                g_store_quad(TAU + (size_t)l * Mp * 256, grow0, 256, row, col, v);
-                g_store_quad(ZB + (size_t)l * Mp * 256, grow0, 256, row, col, z2);
+                g_store_quad_f(TAU + (size_t)l * Mp * 256, grow0, row, col, v);
+                g_store_quad_f(ZB + (size_t)l * Mp * 256, grow0, row, col, z2);
             });
         };
         half(std::integral_constant<int, 0>{});
@@ -323,13 +323,13 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     auto epi_b = [&](f32x16(&acc)[2][2], int l) {   // acc = sbar_l; zbar_{l-1} = phi'(z_{l-1}) sbar_l + second-order term
         auto half = [&](auto NI) {
             float S[8][4], Z2[8][4];
-            prefetch_half<decltype(NI)::value>(S, SACT + (size_t)(l - 1) * Mp * 256, grow0, 256, 2 * wave, lane);
-            prefetch_half<decltype(NI)::value>(Z2, ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, 2 * wave, lane);
+            prefetch_half_f<decltype(NI)::value>(S, SACT + (size_t)(l - 1) * Mp * 256, grow0, 2 * wave, lane);
+            prefetch_half_f<decltype(NI)::value>(Z2, ZB + (size_t)(l - 1) * Mp * 256, grow0, 2 * wave, lane);
             for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(S[b8][i]) * v[i] + Z2[b8][i];
                 lds_store_quad(mainT, col, row, v);
-                g_store_quad(ZB + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
+                g_store_quad_f(ZB + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
             });
         };
         half(std::integral_constant<int, 0>{});
@@ -350,12 +350,12 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += sb[row + i] * w;
             float s[4], z2[4];
-            g_load_quad(SACT + (size_t)7 * Mp * 256, grow0, 256, row, col, s);
-            g_load_quad(ZB + (size_t)7 * Mp * 256, grow0, 256, row, col, z2);
+            g_load_quad_f(SACT + (size_t)7 * Mp * 256, grow0, row, col, s);
+            g_load_quad_f(ZB + (size_t)7 * Mp * 256, grow0, row, col, z2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(s[i]) * v[i] + z2[i];
             lds_store_quad(mainT, col, row, v);
-            g_store_quad(ZB + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+            g_store_quad_f(ZB + (size_t)7 * Mp * 256, grow0, row, col, v);
         });
     }
     __syncthreads();

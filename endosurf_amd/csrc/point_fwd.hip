@@ -274,7 +274,7 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
             lds_store_quad(mainT, col, row, v);
-            g_store_quad(Sl, grow0, 256, row, col, v);
+            g_store_quad_f(Sl, grow0, row, col, v);
         });
     };
     {
@@ -324,7 +324,7 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(v[i]) * w;
             lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(RHO + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
+            if (save) g_store_quad_f(RHO + (size_t)7 * Mp * 256, grow0, row, col, v);
         });
     }
     __syncthreads();
@@ -341,13 +341,13 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
         }
         float S[16][4];                                          // all 16 quads requested at once: one memory round trip
-        prefetch_quads<2, 2>(S, Sl, grow0, 256, 0, 2 * wave, lane);
+        prefetch_quads_f<2, 2>(S, Sl, grow0, 0, 2 * wave, lane);
         __syncthreads();
         for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
             lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(RHO + (size_t)(l - 1) * Mp * 256, grow0, 256, row, col, v);
+            if (save) g_store_quad_f(RHO + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
         });
         if (l == 4)
             for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });

@@ -21,13 +21,14 @@ constexpr int WG_MAX_PROBS = 20;
 struct WgProb {
     const float* X; const float* dA; float* out; float* bias_out;
     int ldx, lda, ldo, M, K, N, bias_stride, task_begin;
+    int x_frag, a_frag;      // operand stored as fragment-ordered [64 x 256] tiles (chain_common.h frag_off) instead of row-major
 };
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k] — a latency-bound HBM stream over X (dA == nullptr means
 // dA = 1: column sums of X).  Every GEMM task of the hosting launch streams a slice of it, half of the tasks before and
 // half after their GEMM, so that the two workgroups of a CU are out of phase and the matrix pipes stay busy meanwhile.
 struct WgSmall {
     const float* X; const float* dA; float* out; float* bias_out;
-    int ldx, lda, ldo, M, K, N, bias_stride;
+    int ldx, lda, ldo, M, K, N, bias_stride, x_frag;
 };
 constexpr int WG_MAX_SMALL = 4;
 struct WgArgs {
@@ -46,6 +47,9 @@ constexpr int WG_R = 16;                         // rows per stage
 constexpr int WG_KW = 128;                       // input features per task
 constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + WG_KW);
 
+// AF / XF: dA / X arrive fragment-ordered (a float4 = 4 consecutive rows of one column: scattered into the row-major LDS
+// panels with four ds_write_b32; the rows of a 16-row stage are the quads q = 2j, 2j+1 of row tile ri, both lane halves)
+template <bool AF, bool XF>
 __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds) {
     constexpr int KW = WG_KW;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,7 +67,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     // of 16): taken from the staging registers on their way to LDS (thread tid holds columns 4*(tid&63).. of rows tid>>6 and
     // 8 + (tid>>6) of every stage), so the MFMA loop stays one branch-free basic block per stage
     const bool do_bias = P.bias_out != nullptr && kb == 0;
-    const float bmask = (do_bias && ((tid >> 6) & (P.bias_stride - 1)) == 0) ? 1.f : 0.f;
+    const float bmask = (do_bias && (AF || ((tid >> 6) & (P.bias_stride - 1)) == 0)) ? 1.f : 0.f;       // AF: stride 1 only
     v4f_t bsum = {0.f, 0.f, 0.f, 0.f};
 
     // global -> register loads of one 16-row stage (two stages in flight: sets 0/1), register -> LDS stores.
@@ -71,23 +75,47 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f vzero = {0.f, 0.f, 0.f, 0.f};
     const int fa1 = tid + WG_THREADS;
+    // row-major operands: thread -> (row, 4 columns); offsets relative to the stage's first row
     const size_t offA0 = (size_t)(tid >> 6) * P.lda + 4 * (tid & 63), offA1 = (size_t)(fa1 >> 6) * P.lda + 4 * (fa1 & 63);
     const int colB = kcol0 + 4 * (tid % (KW / 4));
     const size_t offB = (size_t)(tid / (KW / 4)) * P.ldx + colB;
-    const bool okB = colB < P.ldx;
+    const bool okB = XF || colB < P.ldx;
+    // fragment-ordered operands: unit u -> (wave block u>>8, ni, quad parity qq, lane) of the stage
+    const int fqq = (tid >> 6) & 1, fni = (tid >> 7) & 1, fw = tid >> 8;                // fw in 0..1 (unit tid), +2 for unit tid+512
+    const size_t foffA0 = (size_t)(((fw * 16 + fni * 4 + fqq) * 64 + lane) * 4), foffA1 = foffA0 + (size_t)2 * 16 * 64 * 4;
+    const size_t foffB = (size_t)((((2 * kb + fw) * 16 + fni * 4 + fqq) * 64 + lane) * 4);
+    const int flrow = 8 * fqq + 4 * hi;                                                // first of the 4 local rows of the unit
+    const int flcolA = 64 * fw + 32 * fni + lo, flcolB = 64 * fw + 32 * fni + lo;      // A: + 128 for the second unit
+    auto stage_ptr = [&](const float* base, int ld, bool frag, int m) {
+        return frag ? base + (size_t)(m >> 6) * (64 * 256) + (size_t)((8 * ((m >> 5) & 1) + 2 * ((m >> 4) & 1)) * 256) : base + (size_t)m * ld;
+    };
 #define WG_GLOAD(S, m)                                                                                \
     {                                                                                                 \
-        const float* pa = P.dA + (size_t)(m) * P.lda;                                                 \
-        S##a0 = *reinterpret_cast<const v4f*>(pa + offA0);                                            \
-        S##a1 = *reinterpret_cast<const v4f*>(pa + offA1);                                            \
-        S##b0 = okB ? *reinterpret_cast<const v4f*>(P.X + (size_t)(m) * P.ldx + offB) : vzero;        \
+        const float* pa = stage_ptr(P.dA, P.lda, AF, m);                                              \
+        S##a0 = *reinterpret_cast<const v4f*>(pa + (AF ? foffA0 : offA0));                            \
+        S##a1 = *reinterpret_cast<const v4f*>(pa + (AF ? foffA1 : offA1));                            \
+        const float* px = stage_ptr(P.X, P.ldx, XF, m);                                               \
+        S##b0 = okB ? *reinterpret_cast<const v4f*>(px + (XF ? foffB : offB)) : vzero;                \
     }
 #define WG_SSTORE(S, buf)                                                                             \
     {                                                                                                 \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                         \
-        *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = S##a1;                                         \
-        *reinterpret_cast<v4f*>(Bpan(buf) + 4 * tid) = S##b0;                                         \
-        bsum += bmask * (S##a0 + S##a1);                                                              \
+        if constexpr (AF) {                                                                           \
+            float* la = Apan(buf) + flrow * 256 + flcolA;                                             \
+            la[0] = S##a0[0]; la[256] = S##a0[1]; la[512] = S##a0[2]; la[768] = S##a0[3];             \
+            la[128] = S##a1[0]; la[128 + 256] = S##a1[1]; la[128 + 512] = S##a1[2]; la[128 + 768] = S##a1[3]; \
+            bsum[0] += bmask * (S##a0[0] + S##a0[1] + S##a0[2] + S##a0[3]);                           \
+            bsum[1] += bmask * (S##a1[0] + S##a1[1] + S##a1[2] + S##a1[3]);                           \
+        } else {                                                                                      \
+            *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                     \
+            *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = S##a1;                                     \
+            bsum += bmask * (S##a0 + S##a1);                                                          \
+        }                                                                                             \
+        if constexpr (XF) {                                                                           \
+            float* lb = Bpan(buf) + flrow * KW + flcolB;                                              \
+            lb[0] = S##b0[0]; lb[KW] = S##b0[1]; lb[2 * KW] = S##b0[2]; lb[3 * KW] = S##b0[3];        \
+        } else {                                                                                      \
+            *reinterpret_cast<v4f*>(Bpan(buf) + 4 * tid) = S##b0;                                     \
+        }                                                                                             \
     }
     auto compute = [&](int buf) {
         const float* A = Apan(buf) + nb * 64 + 2 * lo;
@@ -136,14 +164,19 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
                 if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
-    if (do_bias) {      // workgroup-uniform: reduce the 8 row-waves' partial column sums through LDS (all stages consumed)
+    if (do_bias) {      // workgroup-uniform: reduce the partial column sums through LDS (all stages consumed)
         __syncthreads();
-        *reinterpret_cast<v4f*>(lds + 4 * tid) = bsum;
+        if constexpr (AF) {         // 4 threads (qq, hi) per column; unit tid holds column flcolA, unit tid+512 column flcolA + 128
+            lds[(fqq * 2 + hi) * 256 + flcolA] = bsum[0];
+            lds[(fqq * 2 + hi) * 256 + flcolA + 128] = bsum[1];
+        } else {
+            *reinterpret_cast<v4f*>(lds + 4 * tid) = bsum;
+        }
         __syncthreads();
         if (tid < 256) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) s += lds[r * 256 + tid];
+            for (int r = 0; r < (AF ? 4 : 8); ++r) s += lds[r * 256 + tid];
             if (tid < P.N) atomicAdd(P.bias_out + tid, s);
         }
     }
@@ -160,11 +193,25 @@ __device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int
     const int nblk = (P.M + WS_ROWS - 1) / WS_ROWS;
     const int step = 2 * nslots;
     // X rows up to the next multiple of 64 exist (finite padding rows of the workspace; their adjoints are read as 0)
+    typedef float v4f __attribute__((ext_vector_type(4)));
     auto loadx = [&](float(&x)[WS_ROWS], int b0) {
         const int m0 = b0 + half < nblk ? (b0 + half) * WS_ROWS : 0;
-        const float* xp = P.X + (size_t)m0 * P.ldx + k;
+        if (P.x_frag) {     // fragment-ordered [64 x 256] tiles: the 16 rows of column k are 4 float4 (quad parity x lane half)
+            const float* xp = P.X + (size_t)(m0 >> 6) * (64 * 256) + (size_t)((8 * ((m0 >> 5) & 1) + 2 * ((m0 >> 4) & 1)) * 256)
+                              + (size_t)((((k >> 6) * 16 + ((k >> 5) & 1) * 4) * 64 + (k & 31)) * 4);
 #pragma unroll
-        for (int r = 0; r < WS_ROWS; ++r) x[r] = __builtin_nontemporal_load(xp + (size_t)r * P.ldx);
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(xp + (qq * 64 + hh * 32) * 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[8 * qq + 4 * hh + i] = t[i];
+                }
+        } else {
+            const float* xp = P.X + (size_t)m0 * P.ldx + k;
+#pragma unroll
+            for (int r = 0; r < WS_ROWS; ++r) x[r] = __builtin_nontemporal_load(xp + (size_t)r * P.ldx);
+        }
     };
     auto consume = [&](const float(&x)[WS_ROWS], int b0, int it) {
         const bool live = b0 + half < nblk;                                     // half-uniform
@@ -240,7 +287,17 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
         else { const int rem = local - 2 * full; kb = rem & 1; mc = full + (rem >> 1); }
     } else { kb = local % kblk; mc = local / kblk; }
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
-    wgrad_task(P, kb, m0, m1, wlds);
+    if constexpr (NET == 1) {        // only the SDF network's stacks are fragment-ordered
+        if (P.a_frag) {
+            if (P.x_frag) wgrad_task<true, true>(P, kb, m0, m1, wlds);
+            else wgrad_task<true, false>(P, kb, m0, m1, wlds);
+        } else {
+            if (P.x_frag) wgrad_task<false, true>(P, kb, m0, m1, wlds);
+            else wgrad_task<false, false>(P, kb, m0, m1, wlds);
+        }
+    } else {
+        wgrad_task<false, false>(P, kb, m0, m1, wlds);
+    }
     if (!small_first) {
         __syncthreads();
 #pragma unroll 1
@@ -276,6 +333,9 @@ static int launch_group(WgProb* probs, int nprob, const WgSmall* small, int nsma
     for (int i = 0; i < nprob; ++i) {
         ES_REQUIRE(probs[i].lda == 256 && probs[i].M % 64 == 0, "weight-gradient operands must be [64k][256] adjoints");
         ES_REQUIRE((probs[i].bias_stride & (probs[i].bias_stride - 1)) == 0, "bias stride must be a power of two");
+        ES_REQUIRE(!probs[i].a_frag || probs[i].bias_stride == 1 || !probs[i].bias_out, "fragment-ordered adjoints: bias over every row");
+        ES_REQUIRE(!probs[i].x_frag || (probs[i].ldx == 256 && probs[i].K == 256), "fragment-ordered inputs are [64 x 256] tiles");
+        ES_REQUIRE(kid == KID_WGRAD_S || !(probs[i].x_frag || probs[i].a_frag), "fragment-ordered operands: SDF launch only");
         probs[i].task_begin = total;
         total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
         a.p[i] = probs[i];
@@ -306,11 +366,13 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
     WgProb g[WG_MAX_PROBS];
     WgSmall sm[WG_MAX_SMALL];
     int n = 0, ns = 0;
-    auto small = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride) {
-        sm[ns++] = WgSmall{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride};
+    auto small = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride,
+                     int x_frag = 0) {
+        sm[ns++] = WgSmall{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, x_frag};
     };
-    auto add = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride) {
-        g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0};
+    auto add = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride,
+                   int x_frag = 0, int a_frag = 0) {
+        g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0, x_frag, a_frag};
     };
     if (flags & PF_DEFORM) {
         // value + J d rows: (u_l, abar_l) over 2 rows per point (bias gradient from the value rows only); VJP / tangent pair:
@@ -329,21 +391,22 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         // the deformation launch (the longest) stays a pure GEMM: its last layer's slices ride with the two shorter launches
         if (int e = launch_group(g, n, sm, 0, KID_WGRAD_D, M, st)) return e;
     }
-    {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l)
+    {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
+        // kernels (s, rho, tau, zbar) are fragment-ordered (their epilogues load AND store them: one dwordx4 per quad)
         n = 0;
-        add(B(WS_S_S0), 64, B(WS_S_ZB), 256, Mp, 39, 256, dW(NET_S, 0), 39, dB(NET_S, 0), 1);
-        add(B(WS_S_TAU0), 64, B(WS_S_RHO), 256, Mp, 39, 256, dW(NET_S, 0), 39, nullptr, 1);
+        add(B(WS_S_S0), 64, B(WS_S_ZB), 256, Mp, 39, 256, dW(NET_S, 0), 39, dB(NET_S, 0), 1, 0, 1);
+        add(B(WS_S_TAU0), 64, B(WS_S_RHO), 256, Mp, 39, 256, dW(NET_S, 0), 39, nullptr, 1, 0, 1);
         for (int l = 1; l <= 7; ++l) {
             const int K = LAYER_K[NET_S][l];
-            add(B(WS_S_ACT) + (size_t)(l - 1) * t256, 256, B(WS_S_ZB) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, dB(NET_S, l), 1);
-            add(B(WS_S_TAU) + (size_t)(l - 1) * t256, 256, B(WS_S_RHO) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, nullptr, 1);
+            add(B(WS_S_ACT) + (size_t)(l - 1) * t256, 256, B(WS_S_ZB) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, dB(NET_S, l), 1, 1, 1);
+            add(B(WS_S_TAU) + (size_t)(l - 1) * t256, 256, B(WS_S_RHO) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, nullptr, 1, 1, 1);
             if (l == 4) {   // skip layer: encoding columns 256..294
-                add(B(WS_S_S0), 64, B(WS_S_ZB) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1);
-                add(B(WS_S_TAU0), 64, B(WS_S_RHO) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1);
+                add(B(WS_S_S0), 64, B(WS_S_ZB) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, 1);
+                add(B(WS_S_TAU0), 64, B(WS_S_RHO) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, 1);
             }
         }
         if (flags & PF_COLOR)   // feature rows 1..256 of the last layer
-            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1);
+            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1, 1, 0);
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
         ns = 0;
         if (flags & PF_DEFORM) {     // last deformation layer (3 outputs): value + J d rows here, (tau_8, g_c) pair with the colour launch
@@ -351,8 +414,8 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, 2 * Mp, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2);
             if (!(flags & PF_COLOR)) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
         }
-        small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1);   // real rows only: d_sdf is [M]
-        small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1);
+        small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, 1);   // real rows only: d_sdf is [M]
+        small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, 1);
         if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, st)) return e;
     }
     if (flags & PF_COLOR) {

@@ -2,6 +2,8 @@
 //
 // All per-point tensors are row-major [Mp][ld] with Mp = M rounded up to a multiple of 64 so that tiles never
 // need row guards; rows >= M carry finite junk in forward buffers and exact zeros in every adjoint buffer.
+// The four [8][Mp][256] stacks of the SDF kernels (WS_S_ACT, WS_S_RHO, WS_S_TAU, WS_S_ZB) are NOT row-major: each [64 x 256] tile
+// is stored in accumulator-fragment order (chain_common.h frag_off) because the SDF epilogues load and store them per quad.
 // Deformation-network value/JVP buffers have 2 rows per point: row 2p = value, row 2p+1 = tangent along the ray direction d
 // (J d); the VJP sweep (J^T g_c) and the backward's tangent sweep (J gbar_o) have 1 row per point.
 #pragma once
@@ -19,14 +21,14 @@ enum WsBuf : int {
     // forward outputs
     WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB,      // WS_V = J d (3 per point)
     // forward saves
-    WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them)
+    WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them); fragment order
     WS_D_U0,       // [2Mp][64]     deform encoding rows (52 valid)
     WS_D_U,        // [8][2Mp][256] u_1..u_8 (for the weight-gradient GEMMs)
     WS_D_MASK,     // [8][Mp/32][256] uint32: ReLU masks of the value rows, one word per (32-point tile, thread) in the
                    //               accumulator-fragment order of deform_fwd (bit 2*quad + {0,1}); always written
     WS_D_R,        // [8][Mp][256]  VJP sweep: adjoints r_0..r_7 of the pre-activations for the covector g_c
     WS_S_S0,       // [Mp][64]      enc6(x_c) (39 valid)
-    WS_S_RHO,      // [8][Mp][256]  d sdf / d z_0..7
+    WS_S_RHO,      // [8][Mp][256]  d sdf / d z_0..7; fragment order
     WS_S_ADJEPS,   // [Mp][64]      d sdf / d enc6(x_c)
     WS_C_IN,       // [Mp][128]     colour input small part (93 valid)
     WS_C_H,        // [8][Mp][256]  h_1..h_8
@@ -38,8 +40,8 @@ enum WsBuf : int {
     WS_FEATBAR,    // [Mp][256]
     WS_XCBAR_C, WS_GCBAR_C, WS_VBAR_C,     // adjoints of x_c, g_c and v = J d from the colour network
     WS_S_TAU0,     // [Mp][64]
-    WS_S_TAU,      // [8][Mp][256]  tau_1..tau_8
-    WS_S_ZB,       // [8][Mp][256]  second-order terms, overwritten in place by the adjoints of z_0..7
+    WS_S_TAU,      // [8][Mp][256]  tau_1..tau_8; fragment order
+    WS_S_ZB,       // [8][Mp][256]  second-order terms, overwritten in place by the adjoints of z_0..7; fragment order
     WS_XCBAR,
     WS_JU,         // [Mp][3]       J gbar_o (adjoint of g_c through g_o = J^T g_c)
     WS_D_T0,       // [Mp][64]      tangent sweep along gbar_o: encoding tangent (52 valid)

@@ -7,6 +7,6 @@ for r in $(seq ${1:-3}); do
     cp $L/variant_$v.so $L/libendosurf_hip.so
     python bench.py --no-cpu-baseline --steps 30 --warmup 5 | python -c "
 import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(b['ms_per_step'],3), round(b['value']), round(b['roofline']['frac'],3), {k:v for k,v in b['kernel_ms_per_step'].items() if 'wgrad' in k})"
+b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(b['ms_per_step'],3), round(b['value']), round(b['roofline']['frac'],3), {k:v for k,v in b['kernel_ms_per_step'].items() if 'sdf' in k and 'query' not in k})"
   done
 done
