@@ -107,6 +107,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void k(const float4* __restrict__ W, c
     if (sink == 123.456f) out[tid] = sink;
 }
 
+
+// 8 waves per 64-row tile: wave = one 32-column n-tile (RTC = 2, NTC = 1), 4 waves per SIMD at 2 workgroups per CU (<= 128 VGPRs)
+template <int F>
+__global__ __launch_bounds__(512, 4) void k8(const float4* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out, int layers,
+                                              int nlayer_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < MAIN_FLOATS; i += 512) mainT[i] = 1e-3f * (i & 31);
+    __syncthreads();
+    const size_t grow0 = (size_t)blockIdx.x * TM;
+    float sink = 0.f;
+#pragma unroll 1
+    for (int l = 0; l < layers; ++l) {
+        f32x16 acc[2][1];
+        acc_zero(acc);
+        gemm_seg<32, 2, 1, 2>(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 0, wave, lane);
+        if (F & 1) __syncthreads();
+        if (F & 2) {
+            float* ol = out + (size_t)(l & 7) * gridDim.x * TM * 256;
+            const float* il = out + (size_t)((l + 3) & 7) * gridDim.x * TM * 256;
+            for_quads_qi(acc, 0, wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+                const float b = bias[col];
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                if (F & 128) g_load_quad_f(il, grow0, row, col, s);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b + s[i], 0.f);
+                lds_store_quad(mainT, col, row, v);
+                if (F & 4) g_store_quad_f(ol, grow0, row, col, v);
+            });
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[a][0][r];
+        }
+        if (F & 1) __syncthreads();
+    }
+    if (sink == 123.456f) out[tid] = sink;
+}
+template <int F>
+static void run8(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers) {
+    hipFuncSetAttribute((const void*)k8<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k8<F>, dim3(blocks), dim3(512), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k8<F>, dim3(blocks), dim3(512), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    const double fl = 2.0 * 64 * 256 * 256 * (double)layers * blocks;
+    printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+}
+
 template <int F>
 static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers, int stag = 2) {
     hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
@@ -140,6 +195,10 @@ int main() {
     run<16 + 7 + 64>("fragment-order stream-out (dwordx4 stores)", W, bias, out, blocks, layers);
     run<16 + 7 + 128>("row-major load + store per element", W, bias, out, blocks, layers);
     run<16 + 7 + 128 + 64>("fragment-order load + store per element", W, bias, out, blocks, layers);
+    run8<0>("8 waves per tile: gemm_seg only", W, bias, out, blocks, layers);
+    run8<3>("8 waves per tile: + barriers + epilogue", W, bias, out, blocks, layers);
+    run8<7>("8 waves per tile: + fragment-order stream-out", W, bias, out, blocks, layers);
+    run8<7 + 128>("8 waves per tile: fragment-order load + store", W, bias, out, blocks, layers);
     run<3>("same, 512 blocks (one round)", W, bias, out, 512, layers);
     run<3>("same, 256 blocks (1 workgroup per CU)", W, bias, out, 256, layers);
     return 0;
