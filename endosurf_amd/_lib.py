@@ -28,6 +28,10 @@ class es_composite_args(C.Structure):
                                              "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc")])
 
 
+class es_render_args(C.Structure):
+    _fields_ = [("c", es_composite_args), ("ws", C.c_void_p), ("scratch", C.c_void_p), ("flags", C.c_int)]
+
+
 class es_loss_args(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("color_map", "depth_map", "eik", "aux_sdf", "aux_go", "rays", "eod_pts", "color_gt", "depth_gt",
                                             "mask", "cmask", "valid_sn")]
@@ -73,6 +77,11 @@ PROTOTYPES = {
     "es_query_sdf_rays": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _I, _P]),
     "es_march_progress": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
     "es_variance_terms": (_I, [_P, _P, _P, _P, _P]),
+    "es_sample_scratch_floats": (C.c_int64, [_I, _I, _I, _I]),
+    "es_sample_z": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "es_render_scratch_floats": (C.c_int64, [_I, _I]),
+    "es_render_forward": (_I, [C.POINTER(es_render_args), _P, _P, _P]),
+    "es_render_backward": (_I, [C.POINTER(es_render_args), _P, _P, _P, _P]),
     "es_train_aux_points": (_I, [_P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P]),
     "es_adam_step": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_longlong, _P]),
     "es_timing_enable": (_I, [_I]),

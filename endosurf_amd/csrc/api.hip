@@ -238,3 +238,100 @@ int es_adam_step(float* params, const float* grad, float* exp_avg, float* exp_av
 }
 
 }  // extern "C"
+
+// ---- whole-stage calls (the per-kernel entry points above chained like the reference's render_rays / render_core) ----
+static inline size_t up64(size_t n) { return (n + 63) / 64 * 64; }
+int64_t es_sample_scratch_floats(int N, int n_samples, int n_importance, int up_sample_steps) {
+    if (N <= 0 || n_samples <= 0) return 0;
+    const size_t S = (size_t)n_samples + (size_t)(n_importance > 0 ? n_importance : 0);
+    const size_t n_imp = (up_sample_steps > 0 && n_importance > 0) ? (size_t)(n_importance / up_sample_steps) : 0;
+    // z ping-pong [N][S], sdf x3 ([N][n_samples], 2 x [N][S]), merge permutation [N][S] (int32), new depths / their sdf [N][n_imp]
+    return (int64_t)(up64((size_t)N * S) * 4 + up64((size_t)N * n_samples) + 2 * up64((size_t)N * n_imp));
+}
+int es_sample_z(const float* rays, const float* u_perturb, int N, int n_samples, int n_importance, int up_sample_steps, int upsample,
+                const float* packed, const float* weff, int use_deform, float* z_out, float* scratch, void* stream) {
+    ES_REQUIRE(rays && z_out && packed && weff && N >= 0 && n_samples >= 2, "es_sample_z arguments");
+    if (N == 0) return ST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool do_up = upsample && n_importance > 0 && up_sample_steps > 0;
+    const int S = n_samples + (do_up ? n_importance : 0);
+    const float sample_dist = 2.0f / (float)n_samples;
+    if (!do_up) return ray_setup(rays, u_perturb, N, n_samples, sample_dist, 0, z_out, S, nullptr, nullptr, st);
+    ES_REQUIRE(scratch != nullptr && n_importance % up_sample_steps == 0, "es_sample_z needs scratch and n_importance divisible by up_sample_steps");
+    const int n_imp = n_importance / up_sample_steps;
+    const size_t NS = up64((size_t)N * S);
+    float* zbuf[2] = {z_out, scratch};                       // ping-pong; the result must land in z_out
+    float* sdf_a = scratch + NS;
+    float* sdf_b = scratch + 2 * NS;
+    int* src = reinterpret_cast<int*>(scratch + 3 * NS);
+    float* sdf_c0 = scratch + 4 * NS;
+    float* z_new = sdf_c0 + up64((size_t)N * n_samples);
+    float* sdf_new = z_new + up64((size_t)N * n_imp);
+    int cur = up_sample_steps % 2;                            // so that after up_sample_steps swaps the current buffer is z_out
+    if (int e = ray_setup(rays, u_perturb, N, n_samples, sample_dist, 0, zbuf[cur], S, nullptr, nullptr, st)) return e;
+    PointSrc ps{};
+    ps.rays = rays; ps.mode = 1; ps.t_scalar = 0;
+    ps.z = zbuf[cur]; ps.n_per_ray = n_samples; ps.ldz = S; ps.M = N * n_samples;
+    if (int e = query_sdf(ps, packed, weff, sdf_c0, use_deform, st)) return e;
+    const float* sdf_c = sdf_c0;
+    int ld_sdf = n_samples, n = n_samples;
+    for (int i = 0; i < up_sample_steps; ++i) {
+        if (int e = upsample_step(rays, zbuf[cur], S, sdf_c, ld_sdf, N, n, n_imp, 64.f * (float)(1 << i), z_new, zbuf[cur ^ 1], S, src, st)) return e;
+        if (i + 1 != up_sample_steps) {
+            ps.z = z_new; ps.n_per_ray = n_imp; ps.ldz = n_imp; ps.M = N * n_imp;
+            if (int e = query_sdf(ps, packed, weff, sdf_new, use_deform, st)) return e;
+            float* dst = sdf_c != sdf_a ? sdf_a : sdf_b;
+            if (int e = merge_sdf(sdf_c, ld_sdf, sdf_new, n_imp, src, S, N, n, dst, st)) return e;
+            sdf_c = dst; ld_sdf = S;
+        }
+        cur ^= 1;
+        n += n_imp;
+    }
+    return ST_OK;
+}
+
+int64_t es_render_scratch_floats(int N, int S) {
+    if (N <= 0 || S <= 0) return 0;
+    const size_t P = (size_t)N * S;
+    return (int64_t)(up64(P) + up64(P) + 2 * up64(3 * P));     // mid | d_sdf | d_go | d_rgb
+}
+static int render_points(const es_render_args* a, PointSrc& ps, int& flags) {
+    ES_REQUIRE(a && a->c.rays && a->c.z && a->c.variance && a->ws && a->scratch && a->c.N >= 0 && a->c.S >= 1 && a->c.ldz >= a->c.S,
+               "es_render arguments");
+    ps = PointSrc{};
+    ps.rays = a->c.rays; ps.z = a->scratch; ps.mode = 1; ps.n_per_ray = a->c.S; ps.ldz = a->c.S; ps.M = a->c.N * a->c.S;
+    flags = (a->flags & (ES_PF_DEFORM | ES_PF_SAVE)) | ES_PF_COLOR;
+    return ST_OK;
+}
+static CompositeArgs render_composite_args(const es_render_args* a, int flags) {
+    CompositeArgs c = as_comp(&a->c);
+    const WsLayout L = ws_layout(a->c.N * a->c.S, flags);
+    c.sdf = a->ws + L.off[WS_SDF]; c.g_o = a->ws + L.off[WS_GO]; c.rgb = a->ws + L.off[WS_RGB];
+    const size_t P = (size_t)a->c.N * a->c.S;
+    c.d_sdf = a->scratch + up64(P); c.d_go = c.d_sdf + up64(P); c.d_rgb = c.d_go + up64(3 * P);
+    return c;
+}
+int es_render_forward(const es_render_args* a, const float* packed, const float* weff, void* stream) {
+    PointSrc ps; int flags;
+    if (int e = render_points(a, ps, flags)) return e;
+    ES_REQUIRE(packed && weff, "null weights");
+    ES_REQUIRE(a->c.color && a->c.depth && a->c.weights && a->c.cdf && a->c.weight_max && a->c.eik_acc && a->c.wmax_idx, "es_render_forward outputs");
+    if (a->c.N == 0) return ST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = mid_z(a->c.z, a->c.ldz, a->c.N, a->c.S, a->c.sample_dist, a->scratch, st)) return e;
+    if (int e = point_forward(ps, packed, weff, a->ws, flags, 0, st)) return e;
+    return composite(render_composite_args(a, flags), 0, st);
+}
+int es_render_backward(const es_render_args* a, const float* packed, const float* weff, float* dweff, void* stream) {
+    PointSrc ps; int flags;
+    if (int e = render_points(a, ps, flags)) return e;
+    ES_REQUIRE(packed && weff && dweff, "null weights / gradient buffer");
+    ES_REQUIRE(flags & ES_PF_SAVE, "es_render_backward needs a forward run with ES_PF_SAVE");
+    ES_REQUIRE(a->c.g_color && a->c.g_depth && a->c.g_eik && a->c.eik_den && a->c.d_invs_acc, "es_render_backward adjoints");
+    if (a->c.N == 0) return ST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const CompositeArgs c = render_composite_args(a, flags);
+    if (int e = composite(c, 1, st)) return e;
+    if (int e = point_backward_chains(ps, packed, weff, a->ws, flags, 0, c.d_sdf, c.d_go, c.d_rgb, st)) return e;
+    return point_wgrad(ps.M, a->ws, flags, 0, c.d_sdf, dweff, st);
+}

@@ -1,0 +1,102 @@
+"""The whole-stage C entry points (es_sample_z, es_render_forward, es_render_backward) against the drop-in renderer, which issues
+the same launches one by one from Python: forward results must be identical, gradients equal up to the order of fp32 atomics."""
+import ctypes as C
+
+import pytest
+import torch
+
+from gpu_util import renderer_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(use_deform, N=96, seed=5):
+    from endosurf_amd import _lib
+    r = renderer_for(31, "trained", use_deform)
+    from endosurf_amd.trainer import SyntheticScene
+    rays = SyntheticScene("cuda", seed=seed).batch(N)["rays"].contiguous()
+    weff, packed = r._weights()
+    return r, _lib, rays, weff, packed
+
+
+@pytest.mark.parametrize("use_deform", [True, False])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_sample_z_matches_renderer(use_deform, perturb):
+    r, _lib, rays, weff, packed = _setup(use_deform)
+    lib, N = r.engine.lib, rays.shape[0]
+    u = torch.rand(N, 1, device="cuda") if perturb else None
+    with torch.no_grad():
+        z_ref = r.sample_z(rays, iter_step=1, perturb_overwrite=perturb, u_perturb=u)
+    S = r.n_samples + r.n_importance
+    assert z_ref.shape == (N, S)
+    z = torch.full((N, S), float("nan"), device="cuda")
+    scratch = torch.empty(int(lib.es_sample_scratch_floats(N, r.n_samples, r.n_importance, r.up_sample_steps)), device="cuda")
+    _lib.check(lib.es_sample_z(_lib.ptr(rays), _lib.ptr(u) if u is not None else None, N, r.n_samples, r.n_importance, r.up_sample_steps, 1,
+                               _lib.ptr(packed.detach()), _lib.ptr(weff.detach()), int(use_deform), _lib.ptr(z), _lib.ptr(scratch),
+                               _lib.stream_ptr()), "es_sample_z")
+    torch.cuda.synchronize()
+    assert torch.equal(z, z_ref)
+    # coarse samples only
+    z2 = torch.full((N, r.n_samples), float("nan"), device="cuda")
+    _lib.check(lib.es_sample_z(_lib.ptr(rays), None, N, r.n_samples, r.n_importance, r.up_sample_steps, 0, _lib.ptr(packed.detach()),
+                               _lib.ptr(weff.detach()), int(use_deform), _lib.ptr(z2), None, _lib.stream_ptr()), "es_sample_z")
+    with torch.no_grad():
+        r.n_importance, keep = 0, r.n_importance
+        z2_ref = r.sample_z(rays, iter_step=1, perturb_overwrite=False)
+        r.n_importance = keep
+    assert torch.equal(z2, z2_ref)
+
+
+@pytest.mark.parametrize("use_deform", [True, False])
+def test_render_forward_backward_match_renderer(use_deform):
+    r, _lib, rays, weff, packed = _setup(use_deform, N=64)
+    lib, eng, N = r.engine.lib, r.engine, rays.shape[0]
+    with torch.no_grad():
+        z = r.sample_z(rays, iter_step=1, perturb_overwrite=False)
+    S = z.shape[1]
+    sample_dist, cos_anneal = 2.0 / r.n_samples, r.get_cos_anneal_ratio(1)
+    # reference path: the drop-in's render_core + autograd
+    r.zero_grad()
+    ret = r.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist, cos_anneal_ratio=cos_anneal, _rays=rays)
+    g_color = torch.randn(N, 3, device="cuda")
+    g_depth = torch.randn(N, 1, device="cuda")
+    g_eik = torch.tensor(0.3, device="cuda")
+    ((ret["color_map"] * g_color).sum() + (ret["depth_map"] * g_depth).sum() + ret["gradient_o_error"] * g_eik).backward()
+    ref_grad = r.model._flat_grad.clone()
+    ref_dvar = r.model.deviation_network.variance.grad.clone()
+
+    # C path
+    flags = (_lib.PF_DEFORM if use_deform else 0) | _lib.PF_SAVE
+    a = _lib.es_render_args()
+    var = r.model.deviation_network.variance.detach().reshape(1).contiguous()
+    out = dict(color=eng.empty(N, 3), depth=eng.empty(N, 1), weights=eng.empty(N, S), cdf=eng.empty(N, S), weight_max=eng.empty(N, 1),
+               eik_acc=eng.zeros(2), wmax_idx=eng.empty(N, dtype=torch.int32))
+    ws = eng.empty(int(lib.es_point_workspace_floats(N * S, flags | _lib.PF_COLOR)))
+    scratch = eng.empty(int(lib.es_render_scratch_floats(N, S)))
+    a.c.rays, a.c.z, a.c.ldz, a.c.variance = _lib.ptr(rays), _lib.ptr(z), S, _lib.ptr(var)
+    a.c.N, a.c.S, a.c.sample_dist, a.c.cos_anneal = N, S, sample_dist, cos_anneal
+    for k, v in out.items():
+        setattr(a.c, k, _lib.ptr(v))
+    a.ws, a.scratch, a.flags = _lib.ptr(ws), _lib.ptr(scratch), flags
+    wd, pd = weff.detach(), packed.detach()
+    _lib.check(lib.es_render_forward(C.byref(a), _lib.ptr(pd), _lib.ptr(wd), _lib.stream_ptr()), "es_render_forward")
+    torch.cuda.synchronize()
+    assert torch.equal(out["color"], ret["color_map"].detach())
+    assert torch.equal(out["depth"], ret["depth_map"].detach())
+    assert torch.equal(out["weights"], ret["weights"].detach())
+    assert torch.equal(out["cdf"], ret["cdf"].detach())
+    eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
+    eik = (out["eik_acc"][0] / eik_den[0]).item()                  # the eikonal sums are fp32 atomics: equal up to their order
+    assert abs(eik - ret["gradient_o_error"].item()) <= 2e-6 * abs(eik)
+
+    d_invs = eng.zeros(1)
+    dweff = eng.zeros(eng.n_weff)
+    a.c.g_color, a.c.g_depth, a.c.g_eik, a.c.eik_den = _lib.ptr(g_color), _lib.ptr(g_depth.view(-1)), _lib.ptr(g_eik.reshape(1)), _lib.ptr(eik_den)
+    a.c.d_invs_acc = _lib.ptr(d_invs)
+    _lib.check(lib.es_render_backward(C.byref(a), _lib.ptr(pd), _lib.ptr(wd), _lib.ptr(dweff), _lib.stream_ptr()), "es_render_backward")
+    dflat = eng.weightnorm_backward(r.model._flat, dweff, use_deform)
+    dvar = eng.variance_terms(var, d_invs_acc=d_invs)
+    torch.cuda.synchronize()
+    scale = ref_grad.abs().max().item()
+    assert (dflat - ref_grad).abs().max().item() <= 2e-5 * scale
+    assert abs(dvar.item() - ref_dvar.item()) <= 1e-5 * max(abs(ref_dvar.item()), 1e-6)
