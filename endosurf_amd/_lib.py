@@ -79,6 +79,8 @@ PROTOTYPES = {
     "es_variance_terms": (_I, [_P, _P, _P, _P, _P]),
     "es_sample_scratch_floats": (C.c_int64, [_I, _I, _I, _I]),
     "es_sample_z": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "es_march_scratch_floats": (C.c_int64, [_I, _I]),
+    "es_ray_marching": (_I, [_P, _I, _I, _I, C.c_float, _I, _P, _P, _I, _P, _P, _P]),
     "es_render_scratch_floats": (C.c_int64, [_I, _I]),
     "es_render_forward": (_I, [C.POINTER(es_render_args), _P, _P, _P]),
     "es_render_backward": (_I, [C.POINTER(es_render_args), _P, _P, _P, _P]),

@@ -335,3 +335,50 @@ int es_render_backward(const es_render_args* a, const float* packed, const float
     if (int e = point_backward_chains(ps, packed, weff, a->ws, flags, 0, c.d_sdf, c.d_go, c.d_rgb, st)) return e;
     return point_wgrad(ps.M, a->ws, flags, 0, c.d_sdf, dweff, st);
 }
+
+int64_t es_march_scratch_floats(int N, int n_steps) {
+    if (N <= 0 || n_steps <= 0) return 0;
+    // proposals + sdf [N][n_steps], bracket state [N][4], flags / done (int32) [N], d_pred [N], secant points x [N][3], t [N], f_mid [N]
+    return (int64_t)(2 * up64((size_t)N * n_steps) + up64((size_t)N * 4) + 5 * up64((size_t)N) + up64((size_t)N * 3));
+}
+int es_ray_marching(const float* rays, int N, int n_steps, int n_secant, float tau, int block, const float* packed, const float* weff,
+                    int use_deform, float* d_out, float* scratch, void* stream) {
+    ES_REQUIRE(rays && packed && weff && d_out && N >= 0 && n_steps >= 2 && n_secant >= 0, "es_ray_marching arguments");
+    if (N == 0) return ST_OK;
+    ES_REQUIRE(scratch != nullptr, "es_ray_marching needs scratch");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t NP = up64((size_t)N * n_steps), N1 = up64((size_t)N);
+    float* dprop = scratch;
+    float* sdf = dprop + NP;
+    float* state = sdf + NP;
+    int* flags = reinterpret_cast<int*>(state + up64((size_t)N * 4));
+    int* done = flags + N1;
+    float* d_pred = reinterpret_cast<float*>(done + N1);
+    float* t = d_pred + N1;
+    float* f_mid = t + N1;
+    float* x = f_mid + N1;
+    if (int e = ray_setup(rays, nullptr, N, n_steps, 0.f, 1, dprop, n_steps, nullptr, nullptr, st)) return e;
+    PointSrc ps{};
+    ps.rays = rays; ps.mode = 1;
+    if (block > 0 && n_steps % block == 0 && n_steps > block) {
+        if (hipMemsetAsync(sdf, 0, (size_t)N * n_steps * sizeof(float), st) != hipSuccess) return hip_last("es_ray_marching memset");
+        for (int b = 0; b < n_steps / block; ++b) {          // skipped proposals read as 0: no sign change
+            ps.z = dprop + (size_t)b * block; ps.n_per_ray = block; ps.ldz = n_steps; ps.M = N * block;
+            if (int e = query_sdf(ps, packed, weff, sdf + (size_t)b * block, use_deform, st, n_steps, b ? done : nullptr)) return e;
+            if (b + 1 < n_steps / block)
+                if (int e = march_progress(sdf, N, n_steps, (b + 1) * block, tau, done, st)) return e;
+        }
+    } else {
+        ps.z = dprop; ps.n_per_ray = n_steps; ps.ldz = n_steps; ps.M = N * n_steps;
+        if (int e = query_sdf(ps, packed, weff, sdf, use_deform, st)) return e;
+    }
+    if (int e = march_find(sdf, dprop, N, n_steps, tau, state, flags, d_pred, st)) return e;
+    PointSrc pm{};
+    pm.x = x; pm.t = t; pm.mode = 0; pm.n_per_ray = 1; pm.ldz = 1; pm.M = N;
+    for (int i = 0; i < n_secant; ++i) {
+        if (int e = secant_points(rays, d_pred, N, x, t, st)) return e;
+        if (int e = query_sdf(pm, packed, weff, f_mid, use_deform, st)) return e;
+        if (int e = secant_update(f_mid, N, tau, state, d_pred, st)) return e;
+    }
+    return march_finish(d_pred, flags, N, d_out, st);
+}

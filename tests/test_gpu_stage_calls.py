@@ -100,3 +100,18 @@ def test_render_forward_backward_match_renderer(use_deform):
     scale = ref_grad.abs().max().item()
     assert (dflat - ref_grad).abs().max().item() <= 2e-5 * scale
     assert abs(dvar.item() - ref_dvar.item()) <= 1e-5 * max(abs(ref_dvar.item()), 1e-6)
+
+
+@pytest.mark.parametrize("use_deform", [True, False])
+@pytest.mark.parametrize("N,block", [(96, 32), (512, 32), (512, 0)])
+def test_ray_marching_matches_renderer(use_deform, N, block):
+    r, _lib, rays, weff, packed = _setup(use_deform, N=N, seed=9)
+    lib = r.engine.lib
+    with torch.no_grad():
+        d_ref = r.ray_marching(rays)                    # engine path: block-wise only for N * 32 >= 16384, else one launch
+    d = torch.full((N, 1), float("nan"), device="cuda")
+    scratch = torch.empty(int(lib.es_march_scratch_floats(N, 128)), device="cuda")
+    _lib.check(lib.es_ray_marching(_lib.ptr(rays), N, 128, 8, 0.0, block, _lib.ptr(packed.detach()), _lib.ptr(weff.detach()), int(use_deform),
+                                   _lib.ptr(d), _lib.ptr(scratch), _lib.stream_ptr()), "es_ray_marching")
+    torch.cuda.synchronize()
+    assert torch.equal(d, d_ref)
