@@ -149,37 +149,9 @@ __device__ __forceinline__ void for_quads_qi(f32x16 (&acc)[RTC][NTC], int rt0, i
                 f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v, (ri * NTC + ni) * 4 + q);
             }
 }
-// rows row..row+3 of every quad of this wave's tile, from a row-major [rows][ld] HBM buffer, into registers
-template <int RTC, int NTC>
-__device__ __forceinline__ void prefetch_quads(float (&buf)[RTC * NTC * 4][4], const float* __restrict__ base, size_t grow0, int ld,
-                                               int rt0, int nt0, int lane) {
-    const int lo = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int ri = 0; ri < RTC; ++ri)
-#pragma unroll
-        for (int ni = 0; ni < NTC; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* p = base + (grow0 + (rt0 + ri) * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + ni) * 32 + lo;
-                float(&b)[4] = buf[(ri * NTC + ni) * 4 + q];
-                b[0] = __builtin_nontemporal_load(p); b[1] = __builtin_nontemporal_load(p + ld); b[2] = __builtin_nontemporal_load(p + 2 * ld); b[3] = __builtin_nontemporal_load(p + 3 * ld);
-            }
-}
 // The 8 quads (ri, q) of ONE n-tile column block ni of a 64 x 64 wave tile: batch index b8 = ri*4 + q.  Epilogues that read
-// saved activations issue all loads of a half (8 quads per operand = 32 registers) before they touch the first value, so an
-// epilogue pays two memory round trips in total instead of one per compiler-chosen group of quads.
-template <int NI>
-__device__ __forceinline__ void prefetch_half(float (&buf)[8][4], const float* __restrict__ base, size_t grow0, int ld, int nt0, int lane) {
-    const int lo = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* p = base + (grow0 + ri * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + NI) * 32 + lo;
-            float(&b)[4] = buf[ri * 4 + q];
-            b[0] = __builtin_nontemporal_load(p); b[1] = __builtin_nontemporal_load(p + ld); b[2] = __builtin_nontemporal_load(p + 2 * ld); b[3] = __builtin_nontemporal_load(p + 3 * ld);
-        }
-}
+// saved activations issue all loads of a half (prefetch_half_f: 8 quads per operand = 32 registers) before they touch the first
+// value, so an epilogue pays two memory round trips in total instead of one per compiler-chosen group of quads.
 template <int NI, class F>
 __device__ __forceinline__ void for_quads_half(f32x16 (&acc)[2][2], int nt0, int lane, F&& f) {      // f(row, col, v, b8)
     const int lo = lane & 31, hi = lane >> 5;
@@ -190,19 +162,6 @@ __device__ __forceinline__ void for_quads_half(f32x16 (&acc)[2][2], int nt0, int
             float v[4] = {acc[ri][NI][4 * q + 0], acc[ri][NI][4 * q + 1], acc[ri][NI][4 * q + 2], acc[ri][NI][4 * q + 3]};
             f(ri * 32 + 8 * q + 4 * hi, (nt0 + NI) * 32 + lo, v, ri * 4 + q);
         }
-}
-// one value per quad (first row of the quad): ReLU masks of the deformation network's value rows
-template <int RTC, int NTC>
-__device__ __forceinline__ void prefetch_quad_heads(float (&buf)[RTC * NTC * 4], const float* __restrict__ base, size_t grow0, int ld,
-                                                    int rt0, int nt0, int lane) {
-    const int lo = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int ri = 0; ri < RTC; ++ri)
-#pragma unroll
-        for (int ni = 0; ni < NTC; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                buf[(ri * NTC + ni) * 4 + q] = base[(grow0 + (rt0 + ri) * 32 + 8 * q + 4 * hi) * (size_t)ld + (nt0 + ni) * 32 + lo];
 }
 
 __device__ __forceinline__ void lds_store_quad(float* At, int col, int row, const float (&v)[4]) {
