@@ -195,6 +195,12 @@ int main() {
     run<16 + 7 + 64>("fragment-order stream-out (dwordx4 stores)", W, bias, out, blocks, layers);
     run<16 + 7 + 128>("row-major load + store per element", W, bias, out, blocks, layers);
     run<16 + 7 + 128 + 64>("fragment-order load + store per element", W, bias, out, blocks, layers);
+    run<16 + 7 + 32>("stream-out epilogue, odd wave slots start 1 x 3.4 us late", W, bias, out, blocks, layers, 1);
+    run<16 + 7 + 32>("stream-out epilogue, odd wave slots start 2 x 3.4 us late", W, bias, out, blocks, layers, 2);
+    run<16 + 7 + 32>("stream-out epilogue, odd wave slots start 4 x 3.4 us late", W, bias, out, blocks, layers, 4);
+    run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 1 x 3.4 us late", W, bias, out, blocks, layers, 1);
+    run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 2 x 3.4 us late", W, bias, out, blocks, layers, 2);
+    run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 4 x 3.4 us late", W, bias, out, blocks, layers, 4);
     run8<0>("8 waves per tile: gemm_seg only", W, bias, out, blocks, layers);
     run8<3>("8 waves per tile: + barriers + epilogue", W, bias, out, blocks, layers);
     run8<7>("8 waves per tile: + fragment-order stream-out", W, bias, out, blocks, layers);
