@@ -162,6 +162,95 @@ static void run8(const char* name, const float4* W, const float* bias, float* ou
     printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
 }
 
+
+// candidate: the first weight batch of the NEXT layer is requested before this layer's epilogue stores, so that waiting for it
+// does not wait for the stores (gfx9 counts loads and stores in one in-order vmcnt)
+struct WB2 { float4 b[2][2]; };
+__device__ __forceinline__ void wb_load(WB2& w, const float4* __restrict__ W, int nt0, int g0, int lane) {
+    const float4* wl = W + lane;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) w.b[gi][ni] = wl[(size_t)((nt0 + ni) * 32 + g0 + gi) * 64];
+}
+__device__ __forceinline__ void gemm_seg3(f32x16 (&acc)[2][2], const float* At, const float4* __restrict__ W, int nt0, int lane, WB2& b0) {
+    const int lo = lane & 31, hi = lane >> 5;
+    int aoff[2][8];
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aoff[ri][c] = (((ri * 32 + lo) ^ (hi << 2)) ^ (8 * c)) + 64 * hi;
+    auto comp = [&](const WB2& b, const float* Ag) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a[2];
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri) a[ri] = Ag[aoff[ri][4 * (gi & 1) + j] + 512 * gi + 128 * j];
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[ri][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], f4c(b.b[gi][ni], j), acc[ri][ni], 0, 0, 0);
+            }
+    };
+    WB2 b1;
+#pragma unroll 1
+    for (int g0 = 0; g0 < 32; g0 += 4) {
+        wb_load(b1, W, nt0, g0 + 2, lane);
+        comp(b0, At + 512 * g0);
+        if (g0 + 4 < 32) wb_load(b0, W, nt0, g0 + 4, lane);
+        comp(b1, At + 512 * (g0 + 2));
+    }
+}
+template <int F>
+__global__ __launch_bounds__(NTHREADS, 2) void k3(const float4* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                                   int layers, int nlayer_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < MAIN_FLOATS; i += NTHREADS) mainT[i] = 1e-3f * (i & 31);
+    __syncthreads();
+    const size_t grow0 = (size_t)blockIdx.x * TM;
+    WB2 b0;
+    wb_load(b0, W, 2 * wave, 0, lane);
+#pragma unroll 1
+    for (int l = 0; l < layers; ++l) {
+        f32x16 acc[2][2];
+        acc_zero(acc);
+        gemm_seg3(acc, mainT, W + (size_t)(l % nlayer_w) * 8 * 32 * 64, 2 * wave, lane, b0);
+        __syncthreads();
+        wb_load(b0, W + (size_t)((l + 1) % nlayer_w) * 8 * 32 * 64, 2 * wave, 0, lane);      // before the epilogue's stores
+        float* ol = out + (size_t)(l & 7) * gridDim.x * TM * 256;
+        const float* il = out + (size_t)((l + 3) & 7) * gridDim.x * TM * 256;
+        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+            const float b = bias[col];
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            if (F & 128) g_load_quad_f(il, grow0, row, col, s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b + s[i], 0.f);
+            lds_store_quad(mainT, col, row, v);
+            g_store_quad_f(ol, grow0, row, col, v);
+        });
+        __syncthreads();
+    }
+}
+template <int F>
+static void run3(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers) {
+    hipFuncSetAttribute((const void*)k3<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k3<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k3<F>, dim3(blocks), dim3(NTHREADS), LEAN_LDS_BYTES, 0, W, bias, out, layers, 8);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    const double fl = 2.0 * 64 * 256 * 256 * (double)layers * blocks;
+    printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+}
+
 template <int F>
 static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers, int stag = 2) {
     hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
@@ -201,6 +290,8 @@ int main() {
     run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 1 x 3.4 us late", W, bias, out, blocks, layers, 1);
     run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 2 x 3.4 us late", W, bias, out, blocks, layers, 2);
     run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 4 x 3.4 us late", W, bias, out, blocks, layers, 4);
+    run3<0>("first weight batch requested before the epilogue: stream-out", W, bias, out, blocks, layers);
+    run3<128>("first weight batch requested before the epilogue: load+store", W, bias, out, blocks, layers);
     run8<0>("8 waves per tile: gemm_seg only", W, bias, out, blocks, layers);
     run8<3>("8 waves per tile: + barriers + epilogue", W, bias, out, blocks, layers);
     run8<7>("8 waves per tile: + fragment-order stream-out", W, bias, out, blocks, layers);
