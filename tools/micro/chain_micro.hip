@@ -251,6 +251,88 @@ static void run3(const char* name, const float4* W, const float* bias, float* ou
     printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
 }
 
+
+// 32-row tiles: 32 KB of LDS and <= 128 VGPRs per workgroup => FOUR workgroups (4 waves per SIMD) per CU; twice the weight stream
+// per point.  Own k-major layout [k][32 rows] with an XOR swizzle; fragment-ordered stream in / out as above (half tiles).
+__device__ __forceinline__ int swz32(int k, int r) { return k * 32 + (r ^ ((k & 7) << 2)); }
+template <int F>
+__global__ __launch_bounds__(NTHREADS, 4) void k32(const float4* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                                    int layers, int nlayer_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mainT = lds;
+    const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 32 * 256; i += NTHREADS) mainT[i] = 1e-3f * (i & 31);
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 32 * 256;
+    const int nt0 = 2 * wave;
+#pragma unroll 1
+    for (int l = 0; l < layers; ++l) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+        const float4* wl = W + (size_t)(l % nlayer_w) * 8 * 32 * 64 + lane;
+        float4 b0[2][2], b1[2][2];
+        auto loadB = [&](float4(&b)[2][2], int g0) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) b[gi][ni] = wl[(size_t)((nt0 + ni) * 32 + g0 + gi) * 64];
+        };
+        auto comp = [&](const float4(&b)[2][2], int g0) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = mainT[swz32(8 * (g0 + gi) + 2 * j + hi, lo)];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f4c(b[gi][ni], j), acc[ni], 0, 0, 0);
+                }
+        };
+        loadB(b0, 0);
+#pragma unroll 1
+        for (int g0 = 0; g0 < 32; g0 += 4) {
+            loadB(b1, g0 + 2);
+            comp(b0, g0);
+            if (g0 + 4 < 32) loadB(b0, g0 + 4);
+            comp(b1, g0 + 2);
+        }
+        __syncthreads();
+        float* ol = out + (size_t)(l & 7) * gridDim.x * 32 * 256;
+        const float* il = out + (size_t)((l + 3) & 7) * gridDim.x * 32 * 256;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (nt0 + ni) * 32 + lo, row = 8 * q + 4 * hi;
+                const size_t off = base + (size_t)(((wave * 8 + ni * 4 + q) * 64 + lane) * 4);
+                float v[4] = {acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                if (F & 128) { const v4f_frag t = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(il + off)); s[0] = t[0]; s[1] = t[1]; s[2] = t[2]; s[3] = t[3]; }
+                const float b = bias[col];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * 1e-3f + b + s[i], 0.f);
+                *reinterpret_cast<float4*>(&mainT[swz32(col, row)]) = make_float4(v[0], v[1], v[2], v[3]);
+                if (F & 4) { const v4f_frag t = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_frag*>(ol + off)); }
+            }
+        __syncthreads();
+    }
+}
+template <int F>
+static void run32(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k32<F>, dim3(blocks), dim3(NTHREADS), 32 * 256 * 4, 0, W, bias, out, layers, 8);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k32<F>, dim3(blocks), dim3(NTHREADS), 32 * 256 * 4, 0, W, bias, out, layers, 8);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    const double fl = 2.0 * 32 * 256 * 256 * (double)layers * blocks;
+    printf("%-56s %4d blocks %7.3f ms  %6.1f TFLOP/s (%.1f %%)\n", name, blocks, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+}
+
 template <int F>
 static void run(const char* name, const float4* W, const float* bias, float* out, int blocks, int layers, int stag = 2) {
     hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_LDS_BYTES);
@@ -292,6 +374,9 @@ int main() {
     run<16 + 7 + 128 + 64 + 32>("load + store epilogue, odd wave slots 4 x 3.4 us late", W, bias, out, blocks, layers, 4);
     run3<0>("first weight batch requested before the epilogue: stream-out", W, bias, out, blocks, layers);
     run3<128>("first weight batch requested before the epilogue: load+store", W, bias, out, blocks, layers);
+    run32<0>("32-row tiles, 4 workgroups per CU: barriers + epilogue", W, bias, out, 2 * blocks, layers);
+    run32<4>("32-row tiles, 4 workgroups per CU: + stream-out", W, bias, out, 2 * blocks, layers);
+    run32<4 + 128>("32-row tiles, 4 workgroups per CU: load + store", W, bias, out, 2 * blocks, layers);
     run8<0>("8 waves per tile: gemm_seg only", W, bias, out, blocks, layers);
     run8<3>("8 waves per tile: + barriers + epilogue", W, bias, out, blocks, layers);
     run8<7>("8 waves per tile: + fragment-order stream-out", W, bias, out, blocks, layers);
