@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: training rays/s of EndoSurf's renderer hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-Workload = BASELINE config 2: base_pull.yml networks, 1024 rays x (32 coarse + 32 importance) samples per GPU, one FULL
-training step per "step": render (hierarchical sampling + fused MLP stack + compositing) + errorondepth +
-surface_neighbour_error (128-step ray marching + 8 secant steps) + loss + backward + Adam, on synthetic rays/targets
-already resident in HBM, random-init weights (reference initialisation), fp32 throughout.  Weak scaling: every rank
-draws its own 1024-ray batch, one RCCL all-reduce of the 6.6 MB gradient bucket per step.
-Prints ONE JSON line (rank 0).
+N > 1: one rank per GPU over RCCL.  Either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly as ``python bench.py --gpus N``, which re-executes itself under
+torch.distributed.run on 127.0.0.1.
+
+Workloads (BASELINE.json ``configs``; all synthetic rays / targets resident in HBM, reference-initialised weights, fp32):
+  --config 2  (default, the configuration the metric is quoted on) base_pull.yml networks, 1024 rays x (32 coarse + 32 importance)
+              samples per GPU, one FULL training step per "step": render (hierarchical sampling + fused MLP stack + compositing) +
+              errorondepth + surface_neighbour_error (128-step ray marching + 8 secant steps) + loss + backward + Adam.
+  --config 3  base_cut.yml networks, 2048 rays x (64 + 64) samples, same full training step (eikonal gradient included).
+  --config 4  base_d1k1.yml networks (use_deform False), 1024 rays per GPU (4096-ray batch over 4 GPUs), full training step.
+  --config 5  one 640x512 frame per step, forward only, hipGraph-captured 2048-ray chunks, frame rows split over the ranks.
+``--mode forward`` times the renderer forward of the chosen training configuration instead.
+
+``value`` is the DATA-INDEPENDENT step: ray marching evaluates all 128 proposals of every ray, as the reference does.  The early
+exit at each ray's first sign change (bit-identical results, data-dependent saving) is reported next to it as
+``config.with_early_exit``.  Weak scaling: every rank draws its own ray batch, one RCCL all-reduce of the 6.6 MB gradient bucket per
+step.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-RENDER_CFG = dict(net_chunk=80000, anneal_end=50000, n_samples=32, n_importance=32, important_begin_iter=0, up_sample_steps=4,
-                  perturb=True)
 NET_CFG = dict(
     bound=1.0, use_deform=True,
     deform_network=dict(enc_pos_cfg=dict(enc_type="frequency", input_dim=3, multires=6),
@@ -33,15 +42,40 @@ NET_CFG = dict(
                        enc_dir_cfg=dict(enc_type="frequency", input_dim=3, multires=4), n_layers=9, hidden_dim=256, skips=[4],
                        feat_dim=256, out_dim=3),
     deviation_network=dict(init_val=0.3))
-N_RAYS = 1024
+CONFIGS = {
+    2: dict(name="base_pull.yml", rays=1024, n_samples=32, n_importance=32, use_deform=True, mode="train"),
+    3: dict(name="base_cut.yml (64+64 samples: BASELINE.json config 3)", rays=2048, n_samples=64, n_importance=64, use_deform=True, mode="train"),
+    4: dict(name="base_d1k1.yml (use_deform False)", rays=1024, n_samples=32, n_importance=32, use_deform=False, mode="train"),
+    5: dict(name="base_pull.yml", rays=640 * 512, n_samples=32, n_importance=32, use_deform=True, mode="frame"),
+}
 # per-point MACs of the three MLPs (SURVEY 8 / BASELINE.md 2)
 MAC_D, MAC_S, MAC_C = 459520, 544512, 638208
+PEAK_F32_MFMA = 157.3      # TFLOP/s, dense v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 
 
-def flops_per_ray_forward(S_c=32, S_i=32, steps=4):
-    f_up = 2 * (S_c + S_i * (steps - 1) / steps) * (MAC_D + MAC_S)
-    f_core = 2 * (S_c + S_i) * (3 * MAC_D + 2 * MAC_S + MAC_C)      # executed (SURVEY 8d's closed form has 4D: full Jacobian)
-    return f_up, f_core
+def render_cfg(c):
+    return dict(net_chunk=80000, anneal_end=50000, n_samples=c["n_samples"], n_importance=c["n_importance"], important_begin_iter=0,
+                up_sample_steps=4, perturb=True)
+
+
+def algorithmic_gflop_per_ray(c):
+    """SURVEY 8d's closed forms with the executed deformation passes (3D per point instead of 4D: J d and J^T g_c, no full Jacobian)."""
+    D = MAC_D if c["use_deform"] else 0
+    S_c, S_i, steps = c["n_samples"], c["n_importance"], 4
+    f_up = 2 * (S_c + S_i * (steps - 1) / steps) * (D + MAC_S)
+    f_core = 2 * (S_c + S_i) * (3 * D + 2 * MAC_S + MAC_C)
+    f_march = 2 * 128 * (D + MAC_S)
+    return dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9, ray_marching=f_march / 1e9, train_step=(f_up + 3 * f_core + f_march) / 1e9)
+
+
+def kernel_macs(name, use_deform):
+    """Executed MACs per point of each timed kernel.  The deformation network runs as value + JVP (J d) rows (2D), one VJP sweep
+    (J^T g_c, D) and, in the backward, one tangent sweep (J gbar_o, D); SDF 2S (value + reverse / tangent + reverse), colour C; weight
+    gradients the same again; the SDF queries D + S.  Launches whose tiles may exit early are not counted as work."""
+    D = MAC_D if use_deform else 0
+    return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
+            "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D,
+            "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}.get(name)
 
 
 def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
@@ -49,6 +83,7 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
     on a bounded sample of the same workload: full training steps at ``n_rays`` rays.  16 intra-op threads: at these tensor
     sizes (8 192 points x 256 features per GEMM) torch-CPU is fastest there (measured 8/16/32/64/128 threads on the 2 x 64-core
     host: 180 / 213 / 147 / 73 / 26 rays/s); ``cores`` reports the threads actually used."""
+    import torch
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(min(threads, max(1, os.cpu_count() or threads)))
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -57,7 +92,7 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
     from oracle import endosurf_oracle as O
     state = weightgen.make_state(0, "init", True)
     params = {k: torch.tensor(v, requires_grad=True) for k, v in state.items()}
-    R = O.OracleRenderer(O.OracleNet(params, True), RENDER_CFG)
+    R = O.OracleRenderer(O.OracleNet(params, True), render_cfg(CONFIGS[2]))
     opt = torch.optim.Adam(list(params.values()), lr=5e-4)
     rays = torch.from_numpy(weightgen.make_rays(1, n_rays))
     tg = {k: torch.from_numpy(v) for k, v in weightgen.make_targets(2, n_rays).items()}
@@ -81,38 +116,35 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
     cores = torch.get_num_threads()
     torch.set_num_threads(prev_threads)
     return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
-                sample=f"{it} full training steps of the CPU oracle at {n_rays} rays x 64 samples (torch-CPU fp32, autograd), {dt:.2f} s/step")
+                sample=f"{it} full training steps (config 2 networks and loss) of the CPU oracle at {n_rays} rays x 64 samples (a 128-ray sample of "
+                       f"the 1024-ray batch; BASELINE config 1 is the same step at 256 rays), torch-CPU fp32 + autograd, {dt:.2f} s/step",
+                config=dict(n_rays=n_rays, samples_per_ray=64, threads=cores),
+                reference_in_build_container="profiles/reference_cpu.json: the reference itself (imported unmodified), 8 vCPU build container")
 
 
-# executed MACs per point of each kernel.  The deformation network runs as value + JVP (J d) rows (2D), one VJP sweep
-# (J^T g_c, D) and, in the backward, one tangent sweep (J gbar_o, D): 3D per pass instead of SURVEY 8d's 4D (value + three
-# basis tangents); SDF 2S (value + reverse / tangent + reverse), colour C; weight gradients the same again; the SDF query = D + S
-KERNEL_MACS = {"k_query_sdf": MAC_D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S, "k_color_fwd": MAC_C,
-               "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D, "k_wgrad[deform]": 3 * MAC_D,
-               "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}
-
-
-def pmc_traffic(kernel_desc):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/pmc_summary.py); None if no profile matches."""
+def pmc_traffic(symbol):
+    """HBM bytes per launch of a kernel symbol from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/pmc_summary.py), launch-weighted over its launch sizes; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")), key=os.path.getmtime)
     if not files:
         return None
-    kname = kernel_desc.split(" ")[0]
-    rows = [r for r in json.load(open(files[-1])) if r.get("logical", r["kernel"].split("<")[0]) in (kname, kname.split("[")[0])]
+    rows = [r for r in json.load(open(files[-1])) if r.get("logical", r["kernel"].split("<")[0]) == symbol and r.get("hbm_bytes") == r.get("hbm_bytes")]
     if not rows:
         return None
-    r = max(rows, key=lambda r: r["cycles"] * r["launches"])
-    # one timed launch of bench.py may be two kernels (the halves of the deformation launch, point_fwd.hip): sum the
-    # distinct kernels of this name that ran as often as the dominant one
-    parts = {x["kernel"]: x for x in rows if x["launches"] == r["launches"] and x["kernel"] != r["kernel"]}
-    return r["hbm_bytes"] + sum(x["hbm_bytes"] for x in parts.values()), os.path.basename(files[-1])
+    # one timed launch may be two kernels (the halves of the deformation launch, point_fwd.hip): bytes per logical launch =
+    # total bytes / launches of the most frequent instantiation
+    total = sum(r["hbm_bytes"] * r["launches"] for r in rows)
+    by_kernel = {}
+    for r in rows:
+        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0) + r["launches"]
+    return total / max(by_kernel.values()), os.path.basename(files[-1])
 
 
-def kernel_timing(eng, step, first_step, n_steps, record=True):
+def kernel_timing(eng, step, first_step, n_steps, use_deform, record=True):
     """A few extra steps of the SAME workload with the library's HIP-event timers on (events recorded on the launch stream
-    around every chain / weight-gradient kernel).  Kept out of the headline region so the events do not perturb ``value``."""
+    around every chain / query / weight-gradient kernel).  Kept out of the headline region so the events do not perturb ``value``."""
+    import torch
     if record:
         eng.timing_enable(True)
         eng.timing_drain()
@@ -123,23 +155,36 @@ def kernel_timing(eng, step, first_step, n_steps, record=True):
         return {}
     rec = eng.timing_drain()
     eng.timing_enable(False)
-    groups = {}
+    sym = {}              # symbol -> [total ms, launches, total flops]
+    groups = {}           # (symbol, rows) -> [total ms, launches]
     for name, rows, ms in rec:
+        macs = kernel_macs(name, use_deform)
+        s = sym.setdefault(name, [0.0, 0, 0.0])
+        s[0] += ms; s[1] += 1; s[2] += 2.0 * macs * rows if macs else 0.0
         g = groups.setdefault((name, rows), [0.0, 0])
-        g[0] += ms
-        g[1] += 1
-    per_step = {}
-    for (name, rows), (tot, cnt) in groups.items():
-        per_step[name] = per_step.get(name, 0.0) + tot / n_steps
-    out = {"per_step_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
-    cand = [(tot, name, rows, cnt) for (name, rows), (tot, cnt) in groups.items() if name in KERNEL_MACS]
+        g[0] += ms; g[1] += 1
+    out = {"per_step_ms": {k: round(v[0] / n_steps, 4) for k, v in sorted(sym.items(), key=lambda kv: -kv[1][0])}}
+    out["flops_per_step"] = sum(v[2] for v in sym.values()) / n_steps
+    cand = [(v[0], k) for k, v in sym.items() if v[2] > 0]
     if cand:
-        tot, name, rows, cnt = max(cand)
-        out["dominant"] = (f"{name} ({rows} points per launch)", tot / cnt, cnt)
-        out["dominant_flops_per_launch"] = 2.0 * KERNEL_MACS[name] * rows
-        out["all"] = [dict(kernel=n, points=r, launches=c, avg_ms=round(t / c, 4),
-                           tflops=round(2.0 * KERNEL_MACS[n] * r / (t / c * 1e-3) / 1e12, 2)) for t, n, r, c in sorted(cand, reverse=True)]
+        _, name = max(cand)             # dominant kernel = the SYMBOL with the largest total time (as rocprofv3 --stats ranks them)
+        tot, cnt, fl = sym[name]
+        out["dominant"] = dict(kernel=name, avg_launch_ms=tot / cnt, launches=cnt, flops_per_launch=fl / cnt, tflops=fl / (tot * 1e-3) / 1e12,
+                               share_of_timed_kernel_time=tot / sum(v[0] for v in sym.values()))
+    out["symbols"] = [dict(kernel=k, launches_per_step=v[1] / n_steps, ms_per_step=round(v[0] / n_steps, 4),
+                           tflops=round(v[2] / (v[0] * 1e-3) / 1e12, 2) if v[2] else None) for k, v in sorted(sym.items(), key=lambda kv: -kv[1][0])]
+    out["launch_groups"] = [dict(kernel=n, points=r, launches=c, avg_ms=round(t / c, 4),
+                                 tflops=round(2.0 * kernel_macs(n, use_deform) * r / (t / c * 1e-3) / 1e12, 2) if kernel_macs(n, use_deform) else None)
+                            for (n, r), (t, c) in sorted(groups.items(), key=lambda kv: -kv[1][0])]
     return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -147,41 +192,62 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=N_RAYS)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the metric's)")
+    ap.add_argument("--rays", type=int, default=None, help="override the configuration's rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "forward", "frame"])
+    ap.add_argument("--mode", default=None, choices=["train", "forward", "frame"])
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched directly: one rank per GPU under torch.distributed.run on this node (RCCL; rendezvous on 127.0.0.1)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import torch
     from endosurf_amd import EndoSurfRenderer, parallel
     from endosurf_amd.trainer import SyntheticScene, Trainer
+    cfg = dict(CONFIGS[args.config])
+    mode = args.mode or cfg["mode"]
+    if mode == "frame" and cfg["mode"] != "frame":
+        cfg = dict(CONFIGS[5], use_deform=cfg["use_deform"], n_samples=cfg["n_samples"], n_importance=cfg["n_importance"], name=cfg["name"])
+    if args.rays:
+        cfg["rays"] = args.rays
     # one rank per GPU over RCCL ("nccl" on ROCm); ES_DIST_BACKEND=gloo lets the tests drive the N > 1 path on a single GPU
     rank, world, local = parallel.init_distributed(os.environ.get("ES_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
-    assert world == max(1, args.gpus) or args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
-    renderer = EndoSurfRenderer(dict(RENDER_CFG), NET_CFG, device=dev)
+    net_cfg = dict(NET_CFG, use_deform=cfg["use_deform"])
+    renderer = EndoSurfRenderer(render_cfg(cfg), net_cfg, device=dev)
     trainer = Trainer(renderer, data_parallel=world > 1, schedule=args.schedule)
     parallel.broadcast_parameters(trainer.params)
     scene = SyntheticScene(dev, seed=1234 + rank)
-    batches = [scene.batch(args.rays) for _ in range(4)]      # resident in HBM before the timed region
     eng = renderer.engine
-    if args.mode == "frame":
+    S = cfg["n_samples"] + cfg["n_importance"]
+    if mode == "frame":
         # cfg5: one 640x512 frame per step, forward only, fixed 2048-ray chunks through one captured hipGraph; the frame's rows
         # are split across the ranks (no communication; images would be gathered on the host)
         H = 512
         rows = H // world
         frame_rays = scene.frame(H=H, W=640, t=0.5, row0=rank * rows, rows=rows)
-        args.rays = rows * 640
+        n_rays = rows * 640
+    else:
+        n_rays = cfg["rays"]
+        batches = [scene.batch(n_rays) for _ in range(4)]      # resident in HBM before the timed region
 
     def step(i):
-        if args.mode == "frame":
+        if mode == "frame":
             renderer.render_frames(frame_rays, iter_step=1, ray_chunk=args.chunk, perturb_overwrite=False, use_graph=not args.no_graph)
-        elif args.mode == "train":
+        elif mode == "train":
             trainer.update_learning_rate(i + 1)
             trainer.train_step(batches[i % len(batches)], i + 1)
         else:
@@ -193,70 +259,85 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed(first, n):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # headline: the data-independent step (every ray's 128 marching proposals evaluated, like the reference)
+    march_block = eng.march_block
+    if mode == "train":
+        eng.march_block = 0
     for i in range(args.warmup):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    # the same step with ray marching's early exit disabled (all 128 proposals of every ray evaluated, as the reference does):
-    # the data-independent worst case, reported next to the headline value
-    worst = None
-    if args.mode == "train" and eng.march_block:
-        blk, eng.march_block = eng.march_block, 0
-        nw = max(3, args.steps // 3)
-        step(args.warmup + args.steps)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(nw):
-            step(args.warmup + args.steps + 1 + i)
-        barrier()
-        dtw = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dtw], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dtw = float(t.item())
-        eng.march_block = blk
-        worst = dict(ms_per_step=dtw / nw * 1e3, value=world * args.rays * nw / dtw, steps=nw)
+    dt = timed(args.warmup, args.steps)
+    nxt = args.warmup + args.steps
+    # the same step with ray marching's early exit (blocks of 32 proposals; tiles whose rays have all passed their first sign change
+    # return at once; results bit-identical): data-dependent, reported as an extra
+    extra = None
+    if mode == "train" and march_block:
+        eng.march_block = march_block
+        step(nxt)
+        dte = timed(nxt + 1, args.steps)
+        nxt += 1 + args.steps
+        extra = dict(ms_per_step=dte / args.steps * 1e3, value=world * n_rays * args.steps / dte, steps=args.steps, block=march_block,
+                     note="results bit-identical to the headline step; on this synthetic init-weight scene every ray's first sign change "
+                          "falls in the first block of 32 proposals (best case)")
+        eng.march_block = 0
     # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 records timers
-    timing = kernel_timing(eng, step, args.warmup + args.steps + 64, 3, record=(rank == 0))
+    if mode == "frame":
+        # per-kernel durations need eager launches (events cannot be recorded inside the captured graph): a few chunks, eagerly
+        def eager(_i):
+            with torch.no_grad():
+                renderer(frame_rays.reshape(-1, 9)[:args.chunk], iter_step=1, perturb_overwrite=False)
+        eager(0)
+        timing = kernel_timing(eng, eager, 0, 4, cfg["use_deform"], record=(rank == 0))
+        flops_per_step = timing.get("flops_per_step", 0.0) * (n_rays / args.chunk)
+    else:
+        timing = kernel_timing(eng, step, nxt + 64, 3, cfg["use_deform"], record=(rank == 0))
+        flops_per_step = timing.get("flops_per_step", 0.0)
+    eng.march_block = march_block
     ms = dt / args.steps * 1e3
-    value = world * args.rays * args.steps / dt
+    value = world * n_rays * args.steps / dt
 
     if rank == 0:
-        f_up, f_core = flops_per_ray_forward()
-        # dominant kernel: the deformation-network forward (value + 3 tangents): 4 * MAC_D MACs per point, P = rays * 64 points
         roof = None
         if timing.get("dominant"):
-            name, avg_ms, count = timing["dominant"]
-            flops = timing["dominant_flops_per_launch"]
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            tr = pmc_traffic(name)
-            roof = dict(bound="mfma", achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=tr[0] if tr else None,
-                        traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=tr[1] if tr else None, kernel=name,
-                        avg_launch_ms=avg_ms, launches=count, flops_per_launch=flops, peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
-        out = dict(metric={"train": "training rays/sec (1024 rays x 64 samples)", "forward": "forward rays/sec (1024 rays x 64 samples)",
-                           "frame": "full-frame render rays/sec (640x512, 64 samples, %d-ray chunks)" % args.chunk}[args.mode],
+            d = timing["dominant"]
+            tr = pmc_traffic(d["kernel"])
+            e2e = flops_per_step / (ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=d["tflops"], peak=PEAK_F32_MFMA, unit="TFLOP/s", frac=d["tflops"] / PEAK_F32_MFMA,
+                        traffic=tr[0] if tr else None, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        traffic_source=tr[1] if tr else None, kernel=d["kernel"],
+                        kernel_choice="the kernel SYMBOL with the largest total time per step (all its launch sizes together)",
+                        avg_launch_ms=d["avg_launch_ms"], launches=d["launches"], flops_per_launch=d["flops_per_launch"],
+                        share_of_timed_kernel_time=d["share_of_timed_kernel_time"],
+                        end_to_end=dict(achieved=e2e, frac=e2e / PEAK_F32_MFMA, unit="TFLOP/s", flops_per_step=flops_per_step,
+                                        note="executed GEMM FLOPs of one step (2 x MACs x points of every timed launch) / ms_per_step"),
+                        peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
+        what = {"train": "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam",
+                "forward": "renderer forward only",
+                "frame": "one 640x512 frame per step, forward only, hipGraph-captured %d-ray chunks" % args.chunk + (" (eager)" if args.no_graph else "")}[mode]
+        out = dict(metric={"train": "training rays/sec (%d rays x %d samples)" % (n_rays, S), "forward": "forward rays/sec (%d rays x %d samples)" % (n_rays, S),
+                           "frame": "full-frame render rays/sec (640x512, %d samples, %d-ray chunks)" % (S, args.chunk)}[mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                   scaling="strong" if args.mode == "frame" else "weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="base_pull.yml nets, %d rays x (32+32) samples per GPU, %s" % (
-                       args.rays, "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam"
-                       if args.mode == "train" else ("renderer forward only" if args.mode == "forward" else
-                                                     "one 640x512 frame per step, forward only, hipGraph-captured %d-ray chunks" % args.chunk + (" (eager)" if args.no_graph else ""))),
-                       ray_marching=("128 proposals per ray in blocks of %d with early exit at each ray's first sign change (results identical "
-                                     "to evaluating all proposals; the synthetic init-weight scene resolves every ray in the first block)" % eng.march_block
-                                     if eng.march_block else "all 128 proposals per ray"),
-                       without_early_exit=worst,
-                       rays_per_gpu=args.rays, samples_per_ray=64, parallelism=f"dp{world}", weights="reference init, torch.manual_seed(0)",
-                       algorithmic_gflop_per_ray=dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9,
-                                                      train_step=(f_up + 3 * f_core + 2 * 128 * (MAC_D + MAC_S)) / 1e9)),
-                   roofline=roof, kernel_ms_per_step=timing.get("per_step_ms"), kernel_launch_groups=timing.get("all"))
+                   scaling="strong" if mode == "frame" else "weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="BASELINE config %d: %s nets, %d rays x (%d+%d) samples per GPU, %s" % (
+                       args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),
+                       baseline_config=args.config, use_deform=cfg["use_deform"],
+                       ray_marching="all 128 proposals of every ray (data independent, as the reference)" if mode == "train" else None,
+                       with_early_exit=extra, rays_per_gpu=n_rays, samples_per_ray=S, parallelism=f"dp{world}",
+                       weights="reference init, torch.manual_seed(0)", algorithmic_gflop_per_ray=algorithmic_gflop_per_ray(cfg)),
+                   roofline=roof, kernel_ms_per_step=timing.get("per_step_ms"), kernel_symbols=timing.get("symbols"),
+                   kernel_launch_groups=timing.get("launch_groups"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:

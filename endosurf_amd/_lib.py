@@ -25,11 +25,11 @@ class es_composite_args(C.Structure):
                 + [("N", C.c_int), ("S", C.c_int), ("sample_dist", C.c_float), ("cos_anneal", C.c_float)]
                 + [(n, C.c_void_p) for n in ("color", "depth", "weights", "cdf", "weight_max", "eik_acc", "wmax_idx",
                                              "g_color", "g_depth", "g_weights", "g_cdf", "g_wmax", "g_gradients_o", "g_eik",
-                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc")])
+                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc", "ray_part")])
 
 
 class es_render_args(C.Structure):
-    _fields_ = [("c", es_composite_args), ("ws", C.c_void_p), ("scratch", C.c_void_p), ("flags", C.c_int)]
+    _fields_ = [("c", es_composite_args), ("ws", C.c_void_p), ("scratch", C.c_void_p), ("flags", C.c_int), ("wg_scratch", C.c_void_p)]
 
 
 class es_loss_args(C.Structure):
@@ -73,6 +73,8 @@ PROTOTYPES = {
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "es_wgrad_scratch_floats": (C.c_int64, []),
+    "es_point_backward_det": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "es_train_loss": (_I, [C.POINTER(es_loss_args), _P]),
     "es_query_sdf_rays": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _I, _P]),
     "es_march_progress": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
@@ -91,6 +93,7 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
+ABI_VERSION = 2
 PF_DEFORM, PF_COLOR, PF_SAVE = 1, 2, 4
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 
@@ -115,7 +118,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.es_abi_version() != 1:
+    if lib.es_abi_version() != ABI_VERSION:
         raise EndoSurfHipError("libendosurf_hip ABI version mismatch")
     _lib = lib
     return lib
@@ -135,6 +138,7 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """torch's current HIP stream on ``device`` (default: the current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -19,7 +19,8 @@ int variance_terms(const float* variance, const float* d_invs_acc, float* s_val,
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
-int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st);
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
+size_t wgrad_det_floats();
 int train_loss(const LossArgs& a, hipStream_t st);
 int train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
                      float* x, float* t, unsigned char* valid, hipStream_t st);
@@ -213,7 +214,18 @@ int es_point_backward(const es_points* pts, const float* packed, const float* we
     ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
-    return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, (hipStream_t)stream);
+    return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, nullptr, (hipStream_t)stream);
+}
+int64_t es_wgrad_scratch_floats(void) { return (int64_t)wgrad_det_floats(); }
+int es_point_backward_det(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                          const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, float* wg_scratch, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(flags & ES_PF_SAVE, "es_point_backward needs a workspace produced with ES_PF_SAVE");
+    ES_REQUIRE(packed && weff && dweff && (pts->M == 0 || (ws && d_sdf && d_go)), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
+    return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, wg_scratch, (hipStream_t)stream);
 }
 
 int es_train_loss(const es_loss_args* a, void* stream) {
@@ -333,7 +345,7 @@ int es_render_backward(const es_render_args* a, const float* packed, const float
     const CompositeArgs c = render_composite_args(a, flags);
     if (int e = composite(c, 1, st)) return e;
     if (int e = point_backward_chains(ps, packed, weff, a->ws, flags, 0, c.d_sdf, c.d_go, c.d_rgb, st)) return e;
-    return point_wgrad(ps.M, a->ws, flags, 0, c.d_sdf, dweff, st);
+    return point_wgrad(ps.M, a->ws, flags, 0, c.d_sdf, dweff, a->wg_scratch, st);
 }
 
 int64_t es_march_scratch_floats(int N, int n_steps) {

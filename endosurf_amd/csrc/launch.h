@@ -41,6 +41,19 @@ inline int allow_big_lds(K kernel, int bytes) {
     return ST_OK;
 }
 
+// Per-device "has this one-time setup run yet" flag: hipFuncSetAttribute and __constant__ uploads are per device, so a
+// process that drives several GPUs (one Engine per device) must repeat them on each.  Keyed by the CURRENT device
+// (callers run under hipSetDevice / torch.cuda.device of their engine).  Not thread-safe: one host thread per device handle.
+struct DeviceOnce {
+    unsigned long long mask[4] = {0, 0, 0, 0};
+    int dev = 0;
+    bool first() {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) dev = 0;
+        return !((mask[dev >> 6] >> (dev & 63)) & 1ull);
+    }
+    void done() { mask[dev >> 6] |= 1ull << (dev & 63); }
+};
+
 int init_tables();
 
 }  // namespace es

@@ -98,11 +98,12 @@ __global__ __launch_bounds__(1024) void k_train_loss(LossArgs a) {
                 nb[k] = a.w_sn * sgn(n1[k] - n2[k]) / den_sn;        // adjoint of n1 (and minus the adjoint of n2)
                 dot1 += n1[k] * nb[k]; dot2 += n2[k] * nb[k];
             }
-            // n = g/(r+eps):  gbar = (nbar - n (n . nbar) r/(r+eps)) / (r+eps); torch's norm backward gives 0 at r = 0
+            // n = g/d, d = r + eps:  dn_k/dg_j = delta_kj / d - g_k g_j / (r d^2)  =>  gbar = (nbar - n (n . nbar) d/r) / d;
+            // torch's norm backward gives 0 at r = 0
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                o1[k] = r1 > 0.f ? (nb[k] - n1[k] * dot1 * (r1 / d1)) / d1 : nb[k] / d1;
-                o2[k] = r2 > 0.f ? -(nb[k] - n2[k] * dot2 * (r2 / d2)) / d2 : -nb[k] / d2;
+                o1[k] = r1 > 0.f ? (nb[k] - n1[k] * dot1 * (d1 / r1)) / d1 : nb[k] / d1;
+                o2[k] = r2 > 0.f ? -(nb[k] - n2[k] * dot2 * (d2 / r2)) / d2 : -nb[k] / d2;
             }
         }
 #pragma unroll

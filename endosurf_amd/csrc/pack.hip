@@ -20,10 +20,10 @@ __constant__ int c_weff_off[NETS * LAYERS];
 __constant__ int c_p16_segs[P16_COUNT];
 #define P16_SEGS_DEV(i) c_p16_segs[i]
 
-static bool g_tables_ready = false;
+static DeviceOnce g_tables_ready;      // __constant__ tables live per device: upload once on each device that is used
 
 int init_tables() {
-    if (g_tables_ready) return 0;
+    if (!g_tables_ready.first()) return 0;
     SegDev h[SEG_COUNT];
     size_t off = 0;
     for (int i = 0; i < SEG_COUNT; ++i) {
@@ -48,7 +48,7 @@ int init_tables() {
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_param_off), po, sizeof(po)));
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_weff_off), wo, sizeof(wo)));
     ES_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_p16_segs), P16_SEGS, sizeof(P16_SEGS)));
-    g_tables_ready = true;
+    g_tables_ready.done();
     return 0;
 }
 

@@ -598,10 +598,10 @@ constexpr int bwd_lds(int b) {
 template <int B0, int B1>
 static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
     constexpr int lds = bwd_lds(B0) > bwd_lds(B1) ? bwd_lds(B0) : bwd_lds(B1);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;
+    if (attr_done.first()) {
         if (int e = allow_big_lds(k_point_bwd<B0, B1>, lds)) return e;
-        attr_done = true;
+        attr_done.done();
     }
     if (n0 + n1 <= 0) return ST_OK;
     hipLaunchKernelGGL((k_point_bwd<B0, B1>), dim3(n0 + n1), dim3(NTHREADS), lds, st, a, n0, t0, t1);

@@ -140,13 +140,13 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
               int ld_out, const int* ray_done) {
     if (src.M > 0 && src.M <= 8192 && ld_out == 0 && ray_done == nullptr)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;
+    if (attr_done.first()) {
         if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_query_sdf<false, false>, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_query_sdf<true, true>, LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_query_sdf<false, true>, LEAN_LDS_BYTES)) return e;
-        attr_done = true;
+        attr_done.done();
     }
     if (src.M <= 0) return ST_OK;
     const Tabs tb = make_tabs();

@@ -230,7 +230,7 @@ int query_sdf16(const PointSrc& src, const float* packed, const float* weff, flo
     const Tabs tb = make_tabs();
     const dim3 grid((src.M + T16 - 1) / T16), block(NTHREADS);
     const float4* pk = reinterpret_cast<const float4*>(packed);
-    ScopedTimer tm(KID_QUERY, src.M, st);
+    ScopedTimer tm(KID_QUERY16, src.M, st);
     if (use_deform) hipLaunchKernelGGL(k_query_sdf16<true>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
     else hipLaunchKernelGGL(k_query_sdf16<false>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
     return hip_last("query_sdf16");

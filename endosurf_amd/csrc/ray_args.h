@@ -12,5 +12,8 @@ struct CompositeArgs {
     const float* g_color; const float* g_depth; const float* g_weights; const float* g_cdf; const float* g_wmax;
     const float* g_gradients_o; const float* g_eik; const float* eik_den;   // g_eik: scalar adj of gradient_o_error; eik_den = sum relax + 1e-6
     float* d_sdf; float* d_go; float* d_rgb; float* d_invs_acc;            // d_invs_acc[1]: adj of inv_s (atomic)
+    // deterministic mode (nullable): [N][2] floats; the batch sums (eik_acc / d_invs_acc) are then formed from per-ray partials
+    // in a fixed order instead of with fp32 atomics
+    float* ray_part;
 };
 }  // namespace es

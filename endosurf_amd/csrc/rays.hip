@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
         if (lane == 0) {
             a.color[3 * (size_t)ray + 0] = csum[0]; a.color[3 * (size_t)ray + 1] = csum[1]; a.color[3 * (size_t)ray + 2] = csum[2];
             a.depth[ray] = dsum; a.weight_max[ray] = wmx; a.wmax_idx[ray] = wmx_i;
-            atomicAdd(a.eik_acc + 0, e_num); atomicAdd(a.eik_acc + 1, e_den);
+            if (a.ray_part) { a.ray_part[2 * (size_t)ray] = e_num; a.ray_part[2 * (size_t)ray + 1] = e_den; }
+            else { atomicAdd(a.eik_acc + 0, e_num); atomicAdd(a.eik_acc + 1, e_den); }
         }
         return;
     }
@@ -355,7 +356,26 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
         }
     }
     dinvs = wsum(dinvs);
-    if (lane == 0) atomicAdd(a.d_invs_acc, dinvs);
+    if (lane == 0) {
+        if (a.ray_part) a.ray_part[2 * (size_t)ray] = dinvs;
+        else atomicAdd(a.d_invs_acc, dinvs);
+    }
+}
+// deterministic mode: acc[j] += sum_ray part[ray][j] (j < ncol) in a fixed order: strided per-thread sums, then a fixed tree
+__global__ __launch_bounds__(1024) void k_ray_part_reduce(const float* __restrict__ part, int N, int ncol, float* __restrict__ acc) {
+    __shared__ float sh[1024];
+    for (int j = 0; j < ncol; ++j) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < N; i += 1024) s += part[2 * (size_t)i + j];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc[j] += sh[0];
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -503,6 +523,8 @@ int composite(const CompositeArgs& a, int backward, hipStream_t st) {
     if (a.N <= 0) return ST_OK;
     if (backward) hipLaunchKernelGGL(k_composite<true>, ray_grid(a.N), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_composite<false>, ray_grid(a.N), dim3(256), 0, st, a);
+    if (a.ray_part)
+        hipLaunchKernelGGL(k_ray_part_reduce, dim3(1), dim3(1024), 0, st, a.ray_part, a.N, backward ? 1 : 2, backward ? a.d_invs_acc : a.eik_acc);
     return hip_last("composite");
 }
 int march_find(const float* sdf, const float* dprop, int N, int n, float tau, float* state, int* flags, float* d_pred, hipStream_t st) {

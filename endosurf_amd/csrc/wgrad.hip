@@ -5,6 +5,9 @@
 // with fp32 atomics (few row chunks per output tile).  Bias gradients are column sums of dA taken on the fly by the
 // k-block-0 tasks.  The last layers' tiny-N gradients (3 / 1 outputs: an HBM stream over the layer input) are sliced over
 // the GEMM tasks of the same launch.
+// Deterministic mode (a scratch buffer is passed): every task stores its partial tile / column sums / small slices to its own
+// slot of the scratch instead of issuing atomics, and k_wgrad_reduce sums the slots in a FIXED order (one pass per group of
+// problems that accumulate into the same output): bit-identical gradients from run to run, at ~80 MB of extra traffic per launch.
 #include <hip/hip_runtime.h>
 
 #include "arch.h"
@@ -22,20 +25,47 @@ struct WgProb {
     const float* X; const float* dA; float* out; float* bias_out;
     int ldx, lda, ldo, M, K, N, bias_stride, task_begin;
     int x_frag, a_frag;      // operand stored as fragment-ordered [64 x 256] tiles (chain_common.h frag_off) instead of row-major
+    int round;               // deterministic mode: reduction pass (problems accumulating into the same output get consecutive passes)
 };
 // tiny-N layers (3 / 1 outputs): out[n][k] += sum_m dA[m][n] X[m][k] — a latency-bound HBM stream over X (dA == nullptr means
 // dA = 1: column sums of X).  Every GEMM task of the hosting launch streams a slice of it, half of the tasks before and
 // half after their GEMM, so that the two workgroups of a CU are out of phase and the matrix pipes stay busy meanwhile.
 struct WgSmall {
     const float* X; const float* dA; float* out; float* bias_out;
-    int ldx, lda, ldo, M, K, N, bias_stride, x_frag;
+    int ldx, lda, ldo, M, K, N, bias_stride, x_frag, round;
 };
 constexpr int WG_MAX_SMALL = 4;
+constexpr int WG_MAX_TASKS = 512;                // one full round of workgroup slots (launch_group)
 struct WgArgs {
     WgProb p[WG_MAX_PROBS];
     WgSmall s[WG_MAX_SMALL];
     int nprob, total_tasks, MC, nsmall;
+    float* det;              // deterministic mode: scratch of WG_DET_FLOATS floats (nullptr: fp32 atomics)
 };
+// scratch layout: [task][256][128] partial tiles | [task][256] partial bias sums | [small][task][5][256] (4 outputs + bias row)
+constexpr size_t WG_DET_TILE = (size_t)256 * 128;
+constexpr size_t WG_DET_BIAS_OFF = (size_t)WG_MAX_TASKS * WG_DET_TILE;
+constexpr size_t WG_DET_SMALL_OFF = WG_DET_BIAS_OFF + (size_t)WG_MAX_TASKS * 256;
+constexpr size_t WG_DET_FLOATS = WG_DET_SMALL_OFF + (size_t)WG_MAX_SMALL * WG_MAX_TASKS * 5 * 256;
+
+// task index of a problem <-> (k block, row chunk).  The kblk tasks of one row chunk read the same dA rows: they get block ids 8
+// apart (same XCD under the round-robin block -> XCD dispatch, started back to back) so that the second reader hits that XCD's
+// L2 instead of HBM
+__host__ __device__ inline void wg_decode(int local, int kblk, int nchunk, int& kb, int& mc) {
+    if (kblk == 2) {
+        const int grp = local / 16, j = local % 16;
+        const int full = (nchunk / 8) * 8;                 // chunks covered by complete groups of 8
+        if (grp * 8 < full) { mc = grp * 8 + (j & 7); kb = j >> 3; }
+        else { const int rem = local - 2 * full; kb = rem & 1; mc = full + (rem >> 1); }
+    } else { kb = local % kblk; mc = local / kblk; }
+}
+__host__ __device__ inline int wg_encode(int kb, int mc, int kblk, int nchunk) {
+    if (kblk == 2) {
+        const int full = (nchunk / 8) * 8;
+        return mc < full ? (mc / 8) * 16 + (mc & 7) + 8 * kb : 2 * full + (((mc - full) << 1) | kb);
+    }
+    return mc * kblk + kb;
+}
 
 // One workgroup (8 waves) = one task: a [256 x 128] tile of dW (all 256 output features x 128 input features) over a chunk
 // of rows.  Both operand panels are staged through LDS in 16-row stages (double buffered, one barrier per stage, loads two
@@ -49,8 +79,8 @@ constexpr int WG_LDS_FLOATS = 2 * WG_R * (256 + WG_KW);
 
 // AF / XF: dA / X arrive fragment-ordered (a float4 = 4 consecutive rows of one column: scattered into the row-major LDS
 // panels with four ds_write_b32; the rows of a 16-row stage are the quads q = 2j, 2j+1 of row tile ri, both lane halves)
-template <bool AF, bool XF>
-__device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds) {
+template <bool AF, bool XF, bool DET>
+__device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int m1, float* lds, float* det_tile, float* det_bias) {
     constexpr int KW = WG_KW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,7 +191,8 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + t;
-                if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
+                if constexpr (DET) det_tile[n * WG_KW + (k - kcol0)] = acc[t][tp][r];
+                else if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
     if (do_bias) {      // workgroup-uniform: reduce the partial column sums through LDS (all stages consumed)
@@ -177,7 +208,8 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < (AF ? 4 : 8); ++r) s += lds[r * 256 + tid];
-            if (tid < P.N) atomicAdd(P.bias_out + tid, s);
+            if constexpr (DET) det_bias[tid] = s;
+            else if (tid < P.N) atomicAdd(P.bias_out + tid, s);
         }
     }
 }
@@ -185,7 +217,8 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
 // Slice `slot` of `nslots` of a small problem: thread = (input feature k, row-block parity); 16-row blocks, the loads of two
 // steps (2 x 16 rows of X per thread) in flight, the <= 4 adjoint columns go through LDS (double buffered, one barrier per step).
 constexpr int WS_ROWS = 16;
-__device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int nslots, float* lds) {
+template <bool DET>
+__device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int nslots, float* lds, float* det_slot) {
     float(*sd)[WS_ROWS][4] = reinterpret_cast<float(*)[WS_ROWS][4]>(lds);       // [half * 2 + buffer]
     const int tid = threadIdx.x, k = tid & 255, half = tid >> 8;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -253,22 +286,28 @@ __device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int
     }
     __syncthreads();
     if (!half) {
-        for (int n = 0; n < P.N; ++n) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[n] + red[n * 256 + k]);
-        if (P.bias_out && k < P.N) atomicAdd(P.bias_out + k, bsum + red[1024 + k]);
+        if constexpr (DET) {        // det_slot: [5][256] = 4 output rows + bias row of this (small problem, task)
+            for (int n = 0; n < 4; ++n) det_slot[n * 256 + k] = acc[n] + red[n * 256 + k];
+            det_slot[4 * 256 + k] = bsum + red[1024 + k];
+        } else {
+            for (int n = 0; n < P.N; ++n) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[n] + red[n * 256 + k]);
+            if (P.bias_out && k < P.N) atomicAdd(P.bias_out + k, bsum + red[1024 + k]);
+        }
     }
     __syncthreads();
 }
 
 // NET only names the instantiation (0 deform, 1 sdf, 2 colour) so that profilers list the three grouped launches separately
-template <int NET>
+template <int NET, bool DET>
 __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int task = blockIdx.x;
+    auto small_slot = [&](int i) { return DET ? a.det + WG_DET_SMALL_OFF + ((size_t)i * WG_MAX_TASKS + task) * (5 * 256) : nullptr; };
     // blocks b and b + (tasks of the round)/2 tend to share a CU: one of them streams its small slices first, the other last
     const bool small_first = task < a.total_tasks / 2;
     if (small_first)
 #pragma unroll 1
-        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task(a.s[i], task, a.total_tasks, wlds);
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
     int pi = 0;
 #pragma unroll 1
     for (int i = 1; i < a.nprob; ++i)
@@ -276,44 +315,84 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     const WgProb& P = a.p[pi];
     const int local = task - P.task_begin;
     const int kblk = (P.K + WG_KW - 1) / WG_KW;
-    // the kblk tasks of one row chunk read the same dA rows: give them block ids 8 apart (same XCD under the round-robin
-    // block -> XCD dispatch, started back to back) so that the second reader hits that XCD's L2 instead of HBM
     int kb, mc;
-    if (kblk == 2) {
-        const int nchunk = (P.M + a.MC - 1) / a.MC;
-        const int grp = local / 16, j = local % 16;
-        const int full = (nchunk / 8) * 8;                 // chunks covered by complete groups of 8
-        if (grp * 8 < full) { mc = grp * 8 + (j & 7); kb = j >> 3; }
-        else { const int rem = local - 2 * full; kb = rem & 1; mc = full + (rem >> 1); }
-    } else { kb = local % kblk; mc = local / kblk; }
+    wg_decode(local, kblk, (P.M + a.MC - 1) / a.MC, kb, mc);
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
+    float* dt = DET ? a.det + (size_t)task * WG_DET_TILE : nullptr;
+    float* db = DET ? a.det + WG_DET_BIAS_OFF + (size_t)task * 256 : nullptr;
     if constexpr (NET == 1) {        // only the SDF network's stacks are fragment-ordered
         if (P.a_frag) {
-            if (P.x_frag) wgrad_task<true, true>(P, kb, m0, m1, wlds);
-            else wgrad_task<true, false>(P, kb, m0, m1, wlds);
+            if (P.x_frag) wgrad_task<true, true, DET>(P, kb, m0, m1, wlds, dt, db);
+            else wgrad_task<true, false, DET>(P, kb, m0, m1, wlds, dt, db);
         } else {
-            if (P.x_frag) wgrad_task<false, true>(P, kb, m0, m1, wlds);
-            else wgrad_task<false, false>(P, kb, m0, m1, wlds);
+            if (P.x_frag) wgrad_task<false, true, DET>(P, kb, m0, m1, wlds, dt, db);
+            else wgrad_task<false, false, DET>(P, kb, m0, m1, wlds, dt, db);
         }
     } else {
-        wgrad_task<false, false>(P, kb, m0, m1, wlds);
+        wgrad_task<false, false, DET>(P, kb, m0, m1, wlds, dt, db);
     }
     if (!small_first) {
         __syncthreads();
 #pragma unroll 1
-        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task(a.s[i], task, a.total_tasks, wlds);
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
+    }
+}
+
+// Deterministic mode, pass `round`: out += sum of the task slots in ascending row-chunk / task order.  blockIdx.y = problem
+// (GEMM problems first, then the small ones); problems of one pass write disjoint outputs.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgArgs a, int round) {
+    const int pi = blockIdx.y;
+    const int tid0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (pi < a.nprob) {
+        const WgProb& P = a.p[pi];
+        if (P.round != round) return;
+        const int kblk = (P.K + WG_KW - 1) / WG_KW, nchunk = (P.M + a.MC - 1) / a.MC;
+        for (int e = tid0; e < P.N * P.K; e += stride) {
+            const int n = e / P.K, k = e % P.K, kb = k / WG_KW, kk = k % WG_KW;
+            float s = 0.f;
+            for (int mc = 0; mc < nchunk; ++mc)
+                s += a.det[(size_t)(P.task_begin + wg_encode(kb, mc, kblk, nchunk)) * WG_DET_TILE + n * WG_KW + kk];
+            P.out[(size_t)n * P.ldo + k] += s;
+        }
+        if (P.bias_out)
+            for (int n = tid0; n < P.N; n += stride) {
+                float s = 0.f;
+                for (int mc = 0; mc < nchunk; ++mc)
+                    s += a.det[WG_DET_BIAS_OFF + (size_t)(P.task_begin + wg_encode(0, mc, kblk, nchunk)) * 256 + n];
+                P.bias_out[n] += s;
+            }
+    } else {
+        const int i = pi - a.nprob;
+        const WgSmall& P = a.s[i];
+        if (P.round != round) return;
+        const float* base = a.det + WG_DET_SMALL_OFF + (size_t)i * WG_MAX_TASKS * (5 * 256);
+        for (int e = tid0; e < P.N * 256; e += stride) {
+            const int n = e >> 8, k = e & 255;
+            float s = 0.f;
+            for (int t = 0; t < a.total_tasks; ++t) s += base[(size_t)t * (5 * 256) + n * 256 + k];
+            P.out[(size_t)n * P.ldo + k] += s;
+        }
+        if (P.bias_out)
+            for (int n = tid0; n < P.N; n += stride) {
+                float s = 0.f;
+                for (int t = 0; t < a.total_tasks; ++t) s += base[(size_t)t * (5 * 256) + 4 * 256 + n];
+                P.bias_out[n] += s;
+            }
     }
 }
 
 static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
 
-static int launch_group(WgProb* probs, int nprob, const WgSmall* small, int nsmall, int kid, long long rows, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (int e = allow_big_lds(k_wgrad<0>, WG_LDS_FLOATS * 4)) return e;
-        if (int e = allow_big_lds(k_wgrad<1>, WG_LDS_FLOATS * 4)) return e;
-        if (int e = allow_big_lds(k_wgrad<2>, WG_LDS_FLOATS * 4)) return e;
-        attr_done = true;
+static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, int kid, long long rows, float* det, hipStream_t st) {
+    static DeviceOnce attr_done;
+    if (attr_done.first()) {
+        if (int e = allow_big_lds(k_wgrad<0, false>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad<1, false>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad<2, false>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad<0, true>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad<1, true>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad<2, true>, WG_LDS_FLOATS * 4)) return e;
+        attr_done.done();
     }
     if (nprob == 0) return ST_OK;
     ES_REQUIRE(nprob <= WG_MAX_PROBS, "too many weight-gradient problems in one group");
@@ -327,9 +406,11 @@ static int launch_group(WgProb* probs, int nprob, const WgSmall* small, int nsma
     };
     ES_REQUIRE(nsmall <= WG_MAX_SMALL, "too many small weight-gradient problems in one group");
     int MC = 128;
-    while (MC < 65536 && count(MC) > 512) MC += 64;
+    while (MC < 65536 && count(MC) > WG_MAX_TASKS) MC += 64;
+    ES_REQUIRE(count(MC) <= WG_MAX_TASKS, "weight-gradient group does not fit one round of workgroup slots");
     WgArgs a;
-    int total = 0;
+    a.det = det;
+    int total = 0, max_round = 0;
     for (int i = 0; i < nprob; ++i) {
         ES_REQUIRE(probs[i].lda == 256 && probs[i].M % 64 == 0, "weight-gradient operands must be [64k][256] adjoints");
         ES_REQUIRE((probs[i].bias_stride & (probs[i].bias_stride - 1)) == 0, "bias stride must be a power of two");
@@ -338,22 +419,40 @@ static int launch_group(WgProb* probs, int nprob, const WgSmall* small, int nsma
         ES_REQUIRE(kid == KID_WGRAD_S || !(probs[i].x_frag || probs[i].a_frag), "fragment-ordered operands: SDF launch only");
         probs[i].task_begin = total;
         total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
+        probs[i].round = 0;
+        for (int j = 0; j < i; ++j)
+            if (probs[j].out == probs[i].out && probs[j].round >= probs[i].round) probs[i].round = probs[j].round + 1;
+        max_round = probs[i].round > max_round ? probs[i].round : max_round;
         a.p[i] = probs[i];
     }
     a.nprob = nprob; a.total_tasks = total; a.MC = MC; a.nsmall = nsmall;
     for (int i = 0; i < nsmall; ++i) {
         ES_REQUIRE(small[i].K == 256 && small[i].N <= 4, "small weight-gradient problems are [<=4 x 256]");
+        small[i].round = 0;
+        for (int j = 0; j < i; ++j)
+            if (small[j].out == small[i].out && small[j].round >= small[i].round) small[i].round = small[j].round + 1;
+        max_round = small[i].round > max_round ? small[i].round : max_round;
         a.s[i] = small[i];
     }
     const dim3 grid(total);
     ScopedTimer tm(kid, rows, st);
-    if (kid == KID_WGRAD_D) hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
-    else if (kid == KID_WGRAD_S) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
-    else hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    if (det) {
+        if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad<0, true>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+        else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad<1, true>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+        else hipLaunchKernelGGL((k_wgrad<2, true>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+        for (int r = 0; r <= max_round; ++r)
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3(32, nprob + nsmall), dim3(256), 0, st, a, r);
+        return ST_OK;
+    }
+    if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad<0, false>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad<1, false>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
+    else hipLaunchKernelGGL((k_wgrad<2, false>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
     return ST_OK;
 }
+size_t wgrad_det_floats() { return WG_DET_FLOATS; }
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
-int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, hipStream_t st) {
+// ``det`` (nullable): scratch of wgrad_det_floats() floats => deterministic reduction instead of fp32 atomics.
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st) {
     if (M <= 0) return ST_OK;
     const WsLayout L = ws_layout(M, flags);
     const Tabs tb = make_tabs();
@@ -368,11 +467,11 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
     int n = 0, ns = 0;
     auto small = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride,
                      int x_frag = 0) {
-        sm[ns++] = WgSmall{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, x_frag};
+        sm[ns++] = WgSmall{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, x_frag, 0};
     };
     auto add = [&](const float* X, int ldx, const float* dA, int lda, int rows, int K, int N, float* out, int ldo, float* bias, int bstride,
                    int x_frag = 0, int a_frag = 0) {
-        g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0, x_frag, a_frag};
+        g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0, x_frag, a_frag, 0};
     };
     if (flags & PF_DEFORM) {
         // value + J d rows: (u_l, abar_l) over 2 rows per point (bias gradient from the value rows only); VJP / tangent pair:
@@ -389,7 +488,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
                 nullptr, 1);
         }
         // the deformation launch (the longest) stays a pure GEMM: its last layer's slices ride with the two shorter launches
-        if (int e = launch_group(g, n, sm, 0, KID_WGRAD_D, M, st)) return e;
+        if (int e = launch_group(g, n, sm, 0, KID_WGRAD_D, M, det, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
         // kernels (s, rho, tau, zbar) are fragment-ordered (their epilogues load AND store them: one dwordx4 per quad)
@@ -416,7 +515,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         }
         small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, 1);   // real rows only: d_sdf is [M]
         small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, 1);
-        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, st)) return e;
+        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, det, st)) return e;
     }
     if (flags & PF_COLOR) {
         n = 0;
@@ -433,7 +532,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         ns = 0;
         if (flags & PF_DEFORM) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
         small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1);
-        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_C, Mc, st)) return e;
+        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_C, Mc, det, st)) return e;
     }
     return hip_last("point_wgrad");
 }

@@ -34,23 +34,28 @@ def assemble_rays(rays6: torch.Tensor, bounds: torch.Tensor, normalize_time: boo
 
 
 def ray_sampling_importance_from_masks(masks: torch.Tensor) -> torch.Tensor:
-    """Dataset._ray_sampling_importance_from_masks (dataset.py:262-267): pixels often masked out over the sequence get a
-    higher weight in the frames where they are visible.  masks [n,h,w,1] -> importance [n,h,w,1]."""
-    freq = (1.0 - masks).sum(0)
-    p = freq / torch.sqrt((freq ** 2).sum())
-    return masks * (1.0 + p)
+    """Dataset._ray_sampling_importance_from_masks (dataset.py:262-267).  masks [n,h,w,1] -> importance [n,h,w,1]:
+    a visible pixel weighs 1 + (how often that pixel is masked out over the sequence, L2-normalised over the image)."""
+    hidden = masks.shape[0] - masks.sum(dim=0)                 # per pixel: number of frames that mask it out
+    return masks * (1.0 + hidden / torch.linalg.vector_norm(hidden))
+
+
+def sampling_cdf(weights: torch.Tensor, floor: float = 1e-5) -> torch.Tensor:
+    """Normalised running sum of ``weights + floor`` along the last axis: the table the inverse-CDF draw searches."""
+    w = weights + floor
+    return torch.cumsum(w / w.sum(dim=-1, keepdim=True), dim=-1)
 
 
 def importance_sampling_coords(weights: torch.Tensor, n_samples: int, det: bool = False, u: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Dataset._importance_sampling_coords (dataset.py:237-260): inverse-CDF draw of ``n_samples`` indices per row of
-    ``weights`` (searchsorted, right=True).  ``u`` injects the uniform draws (reproducible tests)."""
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
+    """Dataset._importance_sampling_coords (dataset.py:237-260): ``n_samples`` indices per row of ``weights`` drawn by inverting
+    the CDF of (weights + 1e-5) with searchsorted(right=True).  ``det``: evenly spaced quantiles; ``u``: caller-supplied uniform
+    draws (reproducible tests); otherwise torch.rand on the weights' device."""
+    cdf = sampling_cdf(weights)
+    rows = tuple(cdf.shape[:-1])
     if det:
-        u = torch.linspace(0.0, 1.0, steps=n_samples, device=weights.device).expand(list(cdf.shape[:-1]) + [n_samples])
+        u = torch.linspace(0.0, 1.0, n_samples, device=cdf.device).expand(*rows, n_samples)
     elif u is None:
-        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=weights.device)
+        u = torch.rand(*rows, n_samples, device=cdf.device)
     return torch.searchsorted(cdf, u.contiguous(), right=True)
 
 
@@ -79,28 +84,34 @@ class FrameSet:
         self.ray_importance_maps = ray_sampling_importance_from_masks(self.masks)
         self.list_train = list(range(self.n_frames)) if list_train is None else list(list_train)
         self._host_rng = np.random.default_rng(0)
+        # per-frame sampling tables, built once (they depend on the frame only): the CDF over the colour-masked pixels, the
+        # index of the last kept pixel and (lazily) the kept-pixel lists of the uniform branch.  No host round trip per batch.
+        cm = self.color_masks[..., 0].reshape(self.n_frames, -1) == 1.0
+        imp = self.ray_importance_maps[..., 0].reshape(self.n_frames, -1)
+        # sampling over the colour-masked pixels only == sampling over all pixels with the others' weight removed; a zero weight
+        # (instead of the reference's compaction) keeps shapes static.  The 1e-5 floor is applied to kept pixels only
+        wts = torch.where(cm, imp + 1e-5, torch.zeros_like(imp))
+        self._cdf = torch.cumsum(wts / wts.sum(-1, keepdim=True), -1)
+        idx = torch.arange(cm.shape[1], device=dev)
+        self._last_kept = torch.where(cm, idx, torch.zeros_like(idx)).amax(-1)
+        self._cm = cm
+        self._kept = {}
 
     def get_train_batch_data_by_index(self, id_train=None, ray_batch=1024, mask_guided_ray_sampling=True, u=None) -> Dict[str, torch.Tensor]:
         if id_train is None:
             id_train = int(self._host_rng.choice(self.list_train))
         else:
             assert id_train in self.list_train, f"ID {id_train} is not in training list!"
-        cm = self.color_masks[id_train, ..., 0].reshape(-1) == 1.0
         if mask_guided_ray_sampling:
-            # sampling over the colour-masked pixels only == sampling over all pixels with the others' weight removed; a zero
-            # weight (instead of the reference's compaction) keeps shapes static.  The 1e-5 floor is applied to kept pixels only
-            imp = self.ray_importance_maps[id_train, ..., 0].reshape(-1)
-            wts = torch.where(cm, imp + 1e-5, torch.zeros_like(imp))
-            cdf = torch.cumsum(wts / wts.sum(), -1)
             if u is None:
                 u = torch.rand(ray_batch, device=self.device)
-            u = u.reshape(-1).to(self.device)
-            sel = torch.searchsorted(cdf, u.contiguous(), right=True)
+            sel = torch.searchsorted(self._cdf[id_train], u.reshape(-1).to(self.device).contiguous(), right=True)
             # clamp like the reference (max with 0, min with last kept pixel): u -> 1 rounds to the last colour-masked pixel
-            last = torch.nonzero(cm).max()
-            sel = torch.minimum(sel, last)
+            sel = torch.minimum(sel, self._last_kept[id_train])
         else:
-            kept = torch.nonzero(cm).reshape(-1)
+            kept = self._kept.get(id_train)
+            if kept is None:
+                kept = self._kept[id_train] = torch.nonzero(self._cm[id_train]).reshape(-1)      # once per frame
             sel = kept[torch.randperm(kept.numel(), device=self.device)[:ray_batch]]
         pick = lambda a: a[id_train].reshape(self.h * self.w, -1)[sel]
         return {"color": pick(self.colors), "rays": pick(self.rays), "depth": pick(self.depths), "mask": pick(self.masks),

@@ -28,12 +28,35 @@ class Engine:
         self.lib = _lib.load()
         with torch.cuda.device(self.device):
             check(self.lib.es_init(), "es_init")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_param = int(self.lib.es_param_floats())
         self.n_weff = int(self.lib.es_weff_floats())
         self.n_packed = int(self.lib.es_packed_floats())
         import os
         # ray marching evaluates its proposals in blocks of this many steps with early exit (0: one launch over all proposals)
         self.march_block = int(os.environ.get("ES_MARCH_BLOCK", "32"))
+        # deterministic mode: batch sums and weight gradients are reduced in a fixed order instead of with fp32 atomics
+        # (bit-identical results from run to run; a few % slower).  Also settable per renderer: ``renderer.engine.deterministic = True``
+        self.deterministic = os.environ.get("ES_DETERMINISTIC", "0") not in ("0", "", "false", "False")
+        self._wg_scratch = None
+
+    def st(self):
+        """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
+        be inside ``torch.cuda.device(engine.device)`` (the renderer's public methods and autograd's backward are)."""
+        if torch.cuda.current_device() != self.device.index:
+            raise _lib.EndoSurfHipError(
+                f"engine for {self.device} used while the current device is cuda:{torch.cuda.current_device()}; "
+                f"wrap the call in torch.cuda.device({self.device.index})")
+        return stream_ptr(self.device)
+
+    def wg_scratch(self):
+        """Scratch of the deterministic weight-gradient reduction (allocated once, ~80 MB), or None in the default mode."""
+        if not self.deterministic:
+            return None
+        if self._wg_scratch is None:
+            self._wg_scratch = self.empty(int(self.lib.es_wgrad_scratch_floats()))
+        return self._wg_scratch
 
     # ---- buffers ----------------------------------------------------------------------------------
     def empty(self, *shape, dtype=torch.float32):
@@ -48,12 +71,12 @@ class Engine:
         packed = self.empty(self.n_packed)
         if not use_deform:
             weff.zero_()
-        check(self.lib.es_weightnorm_pack(ptr(flat_params), ptr(weff), ptr(packed), int(use_deform), stream_ptr()), "es_weightnorm_pack")
+        check(self.lib.es_weightnorm_pack(ptr(flat_params), ptr(weff), ptr(packed), int(use_deform), self.st()), "es_weightnorm_pack")
         return weff, packed
 
     def weightnorm_backward(self, flat_params, dweff, use_deform: bool):
         dparams = self.zeros(self.n_param)
-        check(self.lib.es_weightnorm_backward(ptr(flat_params), ptr(dweff), ptr(dparams), int(use_deform), stream_ptr()),
+        check(self.lib.es_weightnorm_backward(ptr(flat_params), ptr(dweff), ptr(dparams), int(use_deform), self.st()),
               "es_weightnorm_backward")
         return dparams
 
@@ -88,7 +111,7 @@ class Engine:
 
     def query_sdf(self, pts: es_points, weff, packed, use_deform: bool) -> torch.Tensor:
         out = self.empty(pts.M)
-        check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), stream_ptr()), "es_query_sdf")
+        check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), self.st()), "es_query_sdf")
         return out
 
     # ---- per-ray kernels --------------------------------------------------------------------------
@@ -97,7 +120,7 @@ class Engine:
         near = self.empty(N) if want_bounds else None
         far = self.empty(N) if want_bounds else None
         check(self.lib.es_ray_setup(ptr(rays), ptr(u) if u is not None else None, N, n, float(sample_dist), lin_mode, ptr(z),
-                                    z.shape[1], ptr(near), ptr(far), stream_ptr()), "es_ray_setup")
+                                    z.shape[1], ptr(near), ptr(far), self.st()), "es_ray_setup")
         return near, far
 
     def sample_z(self, rays, u_perturb, weff, packed, use_deform, n_samples, n_importance, up_sample_steps, upsample: bool,
@@ -124,11 +147,11 @@ class Engine:
         z_new = self.empty(N, n_imp)
         for i in range(up_sample_steps):
             check(self.lib.es_upsample_step(ptr(rays), ptr(zc), S, ptr(sdf_c), ld_sdf, N, n, n_imp, float(64 * 2 ** i), ptr(z_new),
-                                            ptr(zn), S, ptr(src), stream_ptr()), "es_upsample_step")
+                                            ptr(zn), S, ptr(src), self.st()), "es_upsample_step")
             if i + 1 != up_sample_steps:
                 sdf_new = self.query_sdf(self.points(rays=rays, z=z_new, n_per_ray=n_imp, ldz=n_imp), weff, packed, use_deform)
                 dst = sdf_a if sdf_c.data_ptr() != sdf_a.data_ptr() else sdf_b
-                check(self.lib.es_merge_sdf(ptr(sdf_c), ld_sdf, ptr(sdf_new), n_imp, ptr(src), S, N, n, ptr(dst), stream_ptr()), "es_merge_sdf")
+                check(self.lib.es_merge_sdf(ptr(sdf_c), ld_sdf, ptr(sdf_new), n_imp, ptr(src), S, N, n, ptr(dst), self.st()), "es_merge_sdf")
                 sdf_c, ld_sdf = dst, S
             zc, zn = zn, zc
             n += n_imp
@@ -139,7 +162,7 @@ class Engine:
     def mid_z(self, z, sample_dist):
         N, S = z.shape
         mid = self.empty(N, S)
-        check(self.lib.es_mid_z(ptr(z), S, N, S, float(sample_dist), ptr(mid), stream_ptr()), "es_mid_z")
+        check(self.lib.es_mid_z(ptr(z), S, N, S, float(sample_dist), ptr(mid), self.st()), "es_mid_z")
         return mid
 
     def composite_args(self, rays, z, sdf, g_o, rgb, variance, sample_dist, cos_anneal) -> es_composite_args:
@@ -149,22 +172,29 @@ class Engine:
         a.sdf, a.g_o, a.rgb, a.variance = ptr(sdf), ptr(g_o), ptr(rgb), ptr(variance)
         a.N, a.S, a.sample_dist, a.cos_anneal = N, S, float(sample_dist), float(cos_anneal)
         a._keep = [rays, z, sdf, g_o, rgb, variance]
+        if self.deterministic:
+            part = self.empty(N, 2)
+            a.ray_part = ptr(part)
+            a._keep.append(part)
         return a
 
-    def composite_forward(self, a: es_composite_args):
+    def composite_forward(self, a: es_composite_args, eik_acc=None):
+        """``eik_acc`` [2] (optional): accumulate the eikonal sums into an existing buffer (chunked renders)."""
         N, S = a.N, a.S
         out = dict(color=self.empty(N, 3), depth=self.empty(N, 1), weights=self.empty(N, S), cdf=self.empty(N, S),
-                   weight_max=self.empty(N, 1), eik_acc=self.zeros(2), wmax_idx=self.empty(N, dtype=torch.int32))
+                   weight_max=self.empty(N, 1), eik_acc=eik_acc if eik_acc is not None else self.zeros(2),
+                   wmax_idx=self.empty(N, dtype=torch.int32))
         for k, v in out.items():
             setattr(a, k, ptr(v))
         a._keep.append(out)
-        check(self.lib.es_composite_forward(C.byref(a), stream_ptr()), "es_composite_forward")
+        check(self.lib.es_composite_forward(C.byref(a), self.st()), "es_composite_forward")
         return out
 
     def composite_backward(self, a: es_composite_args, g_color, g_depth, g_eik, eik_den, g_weights=None, g_cdf=None, g_wmax=None,
-                           g_gradients_o=None):
+                           g_gradients_o=None, d_invs_acc=None):
         N, S = a.N, a.S
-        out = dict(d_sdf=self.empty(N * S), d_go=self.empty(N * S, 3), d_rgb=self.empty(N * S, 3), d_invs_acc=self.zeros(1))
+        out = dict(d_sdf=self.empty(N * S), d_go=self.empty(N * S, 3), d_rgb=self.empty(N * S, 3),
+                   d_invs_acc=d_invs_acc if d_invs_acc is not None else self.zeros(1))
         keep = [g_color, g_depth, g_eik, eik_den, g_weights, g_cdf, g_wmax, g_gradients_o]
         a.g_color, a.g_depth, a.g_eik, a.eik_den = ptr(g_color), ptr(g_depth), ptr(g_eik), ptr(eik_den)
         a.g_weights = ptr(g_weights) if g_weights is not None else None
@@ -174,7 +204,7 @@ class Engine:
         for k, v in out.items():
             setattr(a, k, ptr(v))
         a._keep += keep + [out]
-        check(self.lib.es_composite_backward(C.byref(a), stream_ptr()), "es_composite_backward")
+        check(self.lib.es_composite_backward(C.byref(a), self.st()), "es_composite_backward")
         return out
 
     # ---- ray marching ------------------------------------------------------------------------------
@@ -183,9 +213,9 @@ class Engine:
         out = self.empty(1)
         v = _f32(variance).reshape(1)
         if d_invs_acc is None:
-            check(self.lib.es_variance_terms(ptr(v), None, ptr(out), None, stream_ptr()), "es_variance_terms")
+            check(self.lib.es_variance_terms(ptr(v), None, ptr(out), None, self.st()), "es_variance_terms")
         else:
-            check(self.lib.es_variance_terms(ptr(v), ptr(d_invs_acc), None, ptr(out), stream_ptr()), "es_variance_terms")
+            check(self.lib.es_variance_terms(ptr(v), ptr(d_invs_acc), None, ptr(out), self.st()), "es_variance_terms")
         return out
 
     def march_begin(self, rays, weff, packed, use_deform, n_steps=128, tau=0.0):
@@ -204,15 +234,15 @@ class Engine:
                 p = self.points(rays=rays, z=dprop, n_per_ray=B, ldz=n_steps)
                 p.z = C.c_void_p(dprop.data_ptr() + 4 * b * B)
                 check(self.lib.es_query_sdf_rays(C.byref(p), ptr(packed), ptr(weff), C.c_void_p(sdf.data_ptr() + 4 * b * B), n_steps,
-                                                 ptr(done) if b else None, int(use_deform), stream_ptr()), "es_query_sdf_rays")
+                                                 ptr(done) if b else None, int(use_deform), self.st()), "es_query_sdf_rays")
                 if b + 1 < n_steps // B:
-                    check(self.lib.es_march_progress(ptr(sdf), N, n_steps, (b + 1) * B, float(tau), ptr(done), stream_ptr()), "es_march_progress")
+                    check(self.lib.es_march_progress(ptr(sdf), N, n_steps, (b + 1) * B, float(tau), ptr(done), self.st()), "es_march_progress")
         else:
             sdf = self.query_sdf(self.points(rays=rays, z=dprop, n_per_ray=n_steps, ldz=n_steps), weff, packed, use_deform)
         state = self.empty(N, 4)
         flags = self.empty(N, dtype=torch.int32)
         d_pred = self.empty(N)
-        check(self.lib.es_march_find(ptr(sdf), ptr(dprop), N, n_steps, float(tau), ptr(state), ptr(flags), ptr(d_pred), stream_ptr()),
+        check(self.lib.es_march_find(ptr(sdf), ptr(dprop), N, n_steps, float(tau), ptr(state), ptr(flags), ptr(d_pred), self.st()),
               "es_march_find")
         return dict(rays=rays, weff=weff, packed=packed, use_deform=use_deform, tau=float(tau), state=state, flags=flags, d_pred=d_pred,
                     keep=(dprop, sdf))
@@ -220,7 +250,7 @@ class Engine:
     def march_refine(self, ms, n_secant_steps=8):
         """Second half (endosurf.py:410-449): n_secant_steps dependent secant iterations (latency-bound small launches)."""
         rays, N = ms["rays"], ms["rays"].shape[0]
-        st = stream_ptr()
+        st = self.st()
         x = self.empty(N, 3)
         t = self.empty(N)
         for _ in range(n_secant_steps):
@@ -256,15 +286,16 @@ class PointCtx:
 
 def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
     ctx = PointCtx(self, pts, flags, m_color)
-    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), stream_ptr()), "es_point_forward")
+    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), self.st()), "es_point_forward")
     return ctx
 
 
 Engine.point_forward = _point_forward
 
 
-def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None):
-    """Adjoints of (sdf [M,1], g_o [M,3], rgb [M,3]) -> gradient w.r.t. the effective-weight buffer."""
+def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, dweff=None):
+    """Adjoints of (sdf [M,1], g_o [M,3], rgb [M,3]) -> gradient w.r.t. the effective-weight buffer (accumulated into
+    ``dweff`` if given)."""
     M = ctx.M
     z = lambda g, w: (g.detach().to(torch.float32).contiguous() if g is not None else self.zeros(M, w))
     d_sdf, d_go = z(d_sdf, 1), z(d_go, 3)
@@ -273,9 +304,10 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None):
         mc = ctx.m_color if ctx.m_color > 0 else M
         d_rgb = d_rgb.detach().to(torch.float32).contiguous() if d_rgb is not None else self.zeros(mc, 3)
         assert d_rgb.shape[0] == mc
-    dweff = self.zeros(self.n_weff)
-    check(self.lib.es_point_backward(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
-                                     ptr(d_rgb) if color else None, ptr(dweff), stream_ptr()), "es_point_backward")
+    if dweff is None:
+        dweff = self.zeros(self.n_weff)
+    check(self.lib.es_point_backward_det(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
+                                         ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()), "es_point_backward")
     return dweff
 
 

@@ -8,7 +8,9 @@ every tensor op of the hot path runs inside the C-ABI library; there is no PyTor
 """
 from __future__ import annotations
 
+import functools
 import math
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -45,6 +47,18 @@ def _check_arch(net_cfg: dict):
             if g != v:
                 raise NotImplementedError(
                     f"endosurf_amd kernels are specialised for net.{net}.{k} = {v!r} (all reference EndoSurf configs); got {g!r}")
+
+
+def _on_device(fn):
+    """Run a public renderer method with the renderer's GPU as the current HIP device (the C ABI launches on the current
+    device), so that several renderers on different GPUs can live in one process."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -182,8 +196,113 @@ class EndoSurfNet(nn.Module):
                     out.append((f"{net}.net.{l}.{name}", getattr(mod.net[l], name)))
         return out
 
-    def forward(self, *a, **k):
-        raise RuntimeError("use EndoSurfRenderer; the network is evaluated by fused HIP kernels")
+    # ---- flat-buffer binding -------------------------------------------------------------------------------------------
+    def _rebind(self):
+        """Point every nn.Parameter back at its slot of the flat buffer (Parameter identity is kept, so optimisers stay valid)."""
+        with torch.no_grad():
+            for key, p in self.ordered_params() + [("deviation_network.variance", self.deviation_network.variance)]:
+                off, shape = self._layout[key]
+                p.data = self._flat[off:off + max(1, int(np.prod(shape)))].view(tuple(shape))
+        self._pack_cache = None
+        self._epoch = getattr(self, "_epoch", 0) + 1
+
+    def _apply(self, fn, recurse=True):
+        """``.to() / .cuda() / .float()``: move the FLAT buffer and rebuild the parameter views (nn.Module._apply would give
+        every parameter its own storage and the kernels would keep reading the stale flat buffer)."""
+        new = fn(self._flat)
+        if new.dtype != torch.float32 or new.device.type != "cuda":
+            raise TypeError(f"endosurf_amd parameters live in one fp32 buffer on an AMD GPU (got {new.dtype} on {new.device}); "
+                            "the HIP kernels compute in fp32 only")
+        self._flat = new.contiguous()
+        self._rebind()
+        return self
+
+    def _check_views(self):
+        """Every parameter must still be a view of the flat buffer; anything that re-bound parameter storage (``p.data = ...``
+        loaders, DDP/FSDP flattening, ...) is folded back into it."""
+        base = self._flat.data_ptr()
+        pairs = self.ordered_params() + [("deviation_network.variance", self.deviation_network.variance)]
+        if all(p.data_ptr() == base + 4 * self._layout[k][0] for k, p in pairs):
+            return
+        with torch.no_grad():
+            for k, p in pairs:
+                off, shape = self._layout[k]
+                if p.data_ptr() != base + 4 * off:
+                    if p.dtype != torch.float32:
+                        raise TypeError(f"parameter {k} was converted to {p.dtype}; endosurf_amd computes in fp32 only")
+                    self._flat[off:off + p.numel()].copy_(p.data.reshape(-1).to(self._flat.device))
+        self._rebind()
+
+    # ---- reference query surface (endosurf.py:570-689), evaluated by the fused HIP kernels -------------------------------------
+    # Differentiable w.r.t. the network PARAMETERS (hand-written backward) when grad mode is on; not w.r.t. the query points
+    # (the reference's callers never ask for that: its own uses are under no_grad or go through the renderer).
+    def _r(self):
+        r = self._renderer() if getattr(self, "_renderer", None) is not None else None
+        if r is None:
+            raise RuntimeError("this EndoSurfNet is not attached to an EndoSurfRenderer")
+        return r
+
+    @staticmethod
+    def _xt(x, t):
+        x = x.detach().to(torch.float32).reshape(-1, 3).contiguous()
+        t = torch.as_tensor(t, device=x.device).detach().to(torch.float32).reshape(-1)
+        if t.numel() not in (1, x.shape[0]):
+            raise ValueError("t must hold one time per point (or a single shared time)")
+        return x, (t.expand(x.shape[0]) if t.numel() == 1 else t).contiguous()
+
+    def get_sdf_from_observed_space(self, x, t):
+        """sdf(x + deform(x, t)) [M,1]  (endosurf.py:570-579)."""
+        r = self._r()
+        with torch.cuda.device(r.device):
+            x, t = self._xt(x, t)
+            weff, _ = r._weights()
+            if weff.requires_grad and torch.is_grad_enabled():
+                return r._point_eval(x, t)[0]
+            return r.sdf_observed(x, t)
+
+    def get_sdf_grad_from_observed_space(self, x, t):
+        """d sdf / d x at observed points [M,3] = J^T g_c  (endosurf.py:581-601)."""
+        r = self._r()
+        with torch.cuda.device(r.device):
+            x, t = self._xt(x, t)
+            return r._point_eval(x, t)[1]
+
+    def get_sdf_grad_from_canonical_space(self, x):
+        """d sdf / d x_c at canonical points [M,3]  (endosurf.py:603-619): the SDF network alone."""
+        r = self._r()
+        with torch.cuda.device(r.device):
+            x, t = self._xt(x, torch.zeros(1, device=x.device))
+            return r._point_eval(x, t, canonical=True)[1]
+
+    def get_deform_grad_from_observed_space(self, x, t):
+        """Jacobian d x_c / d x [M,3,3] (dim_out, dim_in)  (endosurf.py:621-658): three forward-mode tangents (J e_j), no grad."""
+        r = self._r()
+        with torch.cuda.device(r.device):
+            x, t = self._xt(x, t)
+            M = x.shape[0]
+            if not self.use_deform:
+                return torch.eye(3, device=x.device).expand(M, 3, 3).clone()
+            weff, packed = r._weights()
+            cols = []
+            with torch.no_grad():
+                for j in range(3):
+                    e = torch.zeros(M, 3, device=x.device)
+                    e[:, j] = 1.0
+                    pctx = r.engine.point_forward(r.engine.points(x=x, t=t, dirs=e), weff.detach(), packed, _lib.PF_DEFORM)
+                    cols.append(pctx.view("v").clone())
+            return torch.stack(cols, dim=-1)
+
+    def forward(self, inputs):
+        """cat([sdf, rgb]) [M,4] for inputs [x, d, t] [M,7]  (endosurf.py:660-689)."""
+        r = self._r()
+        with torch.cuda.device(r.device):
+            inp = inputs.detach().to(torch.float32).reshape(-1, 7)
+            x, t = self._xt(inp[:, :3], inp[:, 6])
+            d = inp[:, 3:6].contiguous()
+            weff, packed = r._weights()
+            pts = r.engine.points(x=x, t=t, dirs=d)
+            sdf, _, rgb = _PointEvalFn.apply(weff, packed, r.engine, pts, r._flags(weff) | _lib.PF_COLOR)
+            return torch.cat([sdf, rgb], -1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -258,26 +377,54 @@ class _PointEvalFn(torch.autograd.Function):
 class _RenderFn(torch.autograd.Function):
     """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing.
     Optionally evaluates ``aux_x/aux_t`` (colour-less points: errorondepth / surface-neighbour points of a training step)
-    in the SAME kernel launches and returns their (sdf, g_o).  ctx keeps inputs and the workspace only, never outputs."""
+    in the SAME kernel launches and returns their (sdf, g_o).  ctx keeps inputs and the workspace only, never outputs.
+
+    ``chunk_rays`` < N with saving enabled: the rays are processed in chunks WITHOUT keeping activations and every chunk is
+    re-evaluated (with saving) in the backward, its weight gradients accumulated: bounded memory for any batch size at the price
+    of one extra forward (the reference bounds memory with run_fn_split's net_chunk, utils.py:114-126, but autograd still keeps
+    every chunk's graph alive; here the bound is real)."""
 
     @staticmethod
-    def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int, aux_x, aux_t):
+    def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int, aux_x, aux_t,
+                chunk_rays: int):
         N, S = z.shape
         P_ = N * S
         ctx.set_materialize_grads(False)          # unused outputs (weights, cdf, ...) arrive as None, not as zero-filled tensors
+        var1 = variance.detach().reshape(1)
+        ctx.eng, ctx.weff, ctx.packed, ctx.variance = eng, weff, packed, variance
+        ctx.geom = (rays, z, float(sample_dist), float(cos_anneal))
+        ctx.flags = flags
+        if (flags & _lib.PF_SAVE) and 0 < chunk_rays < N:
+            ctx.chunk_rays, ctx.pctx, ctx.n_aux = int(chunk_rays), None, 0
+            outs = {k: [] for k in ("color", "depth", "weights", "weight_max", "cdf", "wmax_idx", "go")}
+            eik_acc = eng.zeros(2)
+            for i in range(0, N, chunk_rays):
+                r_, z_ = rays[i:i + chunk_rays], z[i:i + chunk_rays]
+                n_ = r_.shape[0]
+                mid = eng.mid_z(z_, sample_dist)
+                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), weff, packed, (flags & ~_lib.PF_SAVE) | _lib.PF_COLOR)
+                a = eng.composite_args(r_, z_, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
+                out = eng.composite_forward(a, eik_acc=eik_acc)
+                for k in ("color", "depth", "weights", "weight_max", "cdf", "wmax_idx"):
+                    outs[k].append(out[k])
+                outs["go"].append(pctx.view("go")[:n_ * S].view(n_, S, 3).clone())
+            cat = {k: torch.cat(v, 0) for k, v in outs.items()}
+            ctx.eik_den = (eik_acc[1] + 1e-6).reshape(1)
+            eik = eik_acc[0] / ctx.eik_den[0]
+            ctx.mark_non_differentiable(cat["wmax_idx"])
+            return (cat["color"], cat["depth"], cat["go"], eik, cat["weights"], cat["weight_max"], cat["cdf"], cat["wmax_idx"],
+                    eng.zeros(0, 1), eng.zeros(0, 3))
+        ctx.chunk_rays = 0
         mid = eng.mid_z(z, sample_dist)
         fused = aux_x is not None and aux_x.shape[0] > 0 and P_ % 64 == 0
         pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=aux_x if fused else None, t=aux_t if fused else None)
         pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR, m_color=P_ if fused else 0)
-        var1 = variance.detach().reshape(1)
         sdf_all, go_all = pctx.view("sdf"), pctx.view("go")
         a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
         out = eng.composite_forward(a)
         eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
         eik = out["eik_acc"][0] / eik_den[0]
-        ctx.eng, ctx.pctx, ctx.eik_den = eng, pctx, eik_den
-        ctx.weff, ctx.packed, ctx.variance = weff, packed, variance
-        ctx.geom = (rays, z, float(sample_dist), float(cos_anneal))
+        ctx.pctx, ctx.eik_den = pctx, eik_den
         ctx.n_aux = aux_x.shape[0] if fused else 0
         gradients_o = go_all[:P_].view(N, S, 3).clone()           # own storage: the 8 GB workspace must not outlive backward
         aux_sdf = sdf_all[P_:].clone() if fused else eng.zeros(0, 1)
@@ -287,29 +434,43 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go):
-        eng, pctx = ctx.eng, ctx.pctx
-        if not (pctx.flags & _lib.PF_SAVE):
+        eng = ctx.eng
+        if not (ctx.flags & _lib.PF_SAVE):
             raise RuntimeError("render was run without saved activations; cannot backpropagate")
         rays, zs, sample_dist, cos_anneal = ctx.geom
         N, S = zs.shape
-        P_ = N * S
         var = ctx.variance.detach()
-        a = eng.composite_args(rays, zs, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var.reshape(1), sample_dist, cos_anneal)
+        var1 = var.reshape(1)
         z = lambda g, *shape: (g.contiguous() if g is not None else eng.zeros(*shape))
-        bw = eng.composite_backward(a, z(g_color, N, 3), z(g_depth, N, 1).view(-1), z(g_eik, 1).reshape(1), ctx.eik_den,
-                                    g_weights=g_weights.contiguous() if g_weights is not None else None,
-                                    g_cdf=g_cdf.contiguous() if g_cdf is not None else None,
-                                    g_wmax=g_wmax.contiguous().view(-1) if g_wmax is not None else None,
-                                    g_gradients_o=g_go.contiguous() if g_go is not None else None)
-        d_sdf, d_go = bw["d_sdf"].view(-1, 1), bw["d_go"]
-        if ctx.n_aux:
-            d_sdf = torch.cat([d_sdf, z(g_aux_sdf, ctx.n_aux, 1)], 0)
-            d_go = torch.cat([d_go, z(g_aux_go, ctx.n_aux, 3)], 0)
-        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"])
+        opt = lambda g: g.contiguous() if g is not None else None
+        g_color, g_depth, g_eik = z(g_color, N, 3), z(g_depth, N, 1).view(-1), z(g_eik, 1).reshape(1)
+        g_weights, g_cdf, g_go = opt(g_weights), opt(g_cdf), opt(g_go)
+        g_wmax = g_wmax.contiguous().view(-1) if g_wmax is not None else None
+        sl = lambda g, i, j: g[i:j] if g is not None else None
+        d_invs_acc = eng.zeros(1)
+        dweff = None
+        C = ctx.chunk_rays if ctx.chunk_rays else N
+        for i in range(0, N, C):
+            j = min(i + C, N)
+            if ctx.chunk_rays:          # re-evaluate this chunk with saving
+                r_, z_ = rays[i:j], zs[i:j]
+                mid = eng.mid_z(z_, sample_dist)
+                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), ctx.weff, ctx.packed, ctx.flags | _lib.PF_COLOR)
+            else:
+                r_, z_, pctx = rays, zs, ctx.pctx
+            a = eng.composite_args(r_, z_, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
+            bw = eng.composite_backward(a, g_color[i:j], g_depth[i:j], g_eik, ctx.eik_den, g_weights=sl(g_weights, i, j), g_cdf=sl(g_cdf, i, j),
+                                        g_wmax=sl(g_wmax, i, j), g_gradients_o=sl(g_go, i, j), d_invs_acc=d_invs_acc)
+            d_sdf, d_go = bw["d_sdf"].view(-1, 1), bw["d_go"]
+            if ctx.n_aux:
+                d_sdf = torch.cat([d_sdf, z(g_aux_sdf, ctx.n_aux, 1)], 0)
+                d_go = torch.cat([d_go, z(g_aux_go, ctx.n_aux, 3)], 0)
+            dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"], dweff=dweff)
+            del pctx
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852): d var = d inv_s * 10 exp(10 var) inside the clip range
-        dvar = eng.variance_terms(var, d_invs_acc=bw["d_invs_acc"]).reshape(ctx.variance.shape)
+        dvar = eng.variance_terms(var, d_invs_acc=d_invs_acc).reshape(ctx.variance.shape)
         ctx.pctx = None                                           # release the workspace as soon as it has been consumed
-        return dweff, None, dvar, None, None, None, None, None, None, None, None
+        return dweff, None, dvar, None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -327,6 +488,7 @@ class EndoSurfRenderer(nn.Module):
         self.net_cfg = net_cfg
         self.engine = Engine(self.device)          # raises if not an AMD GPU / library missing: no fallback
         self.model = EndoSurfNet(net_cfg, self.device)
+        self.model._renderer = weakref.ref(self)
         self.model._pack_cache = None
         self.model._flat_grad = None
         self.model._epoch = 0            # bumped by in-place updates that bypass torch's version counters (trainer.FlatAdam)
@@ -338,6 +500,10 @@ class EndoSurfRenderer(nn.Module):
         self.up_sample_steps = render_cfg["up_sample_steps"]
         self.net_chunk = render_cfg["net_chunk"]
         self.use_deform = self.model.use_deform
+        # Training keeps ~103 KB of activations per point for the hand-written backward (csrc/workspace.h).  A render whose
+        # workspace would exceed this budget is split into ray chunks that are RE-EVALUATED in the backward (forward without
+        # saving, then per chunk: forward with saving + backward, gradients accumulated), so memory stays bounded for any batch.
+        self.workspace_gb = float(render_cfg.get("workspace_gb", os.environ.get("ES_WORKSPACE_GB", "64")))
 
     # ---- reference API: parameters / checkpoints -------------------------------------------------------------
     def get_train_params(self):
@@ -357,6 +523,7 @@ class EndoSurfRenderer(nn.Module):
     # ---- weights: weight-norm + MFMA packing once per parameter version ------------------------------------------
     def _weights(self):
         m = self.model
+        m._check_views()
         plist = [p for _, p in m.ordered_params()]
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
         key = ((tuple(p._version for p in plist), m._epoch), want_grad)
@@ -383,10 +550,30 @@ class EndoSurfRenderer(nn.Module):
     def _rays32(rays):
         return rays.detach().to(torch.float32).contiguous()
 
+    def _chunk_rays(self, N, S, flags):
+        """Rays per chunk of a grad-enabled render such that its activation workspace stays within ``workspace_gb`` (0: no chunking)."""
+        if not (flags & _lib.PF_SAVE):
+            return 0
+        key = (flags, self.workspace_gb)
+        cache = self.__dict__.setdefault("_budget_points", {})
+        if key not in cache:
+            per_point = 4.0 * self.engine.lib.es_point_workspace_floats(65536, flags | _lib.PF_COLOR) / 65536
+            cache[key] = (self.workspace_gb * 1e9 / per_point, per_point)
+        budget, per_point = cache[key]
+        if N * S <= budget:
+            return 0
+        c = int(budget / S) // 64 * 64
+        if c < 64:
+            raise _lib.EndoSurfHipError(
+                f"render_cfg['workspace_gb'] = {self.workspace_gb} GB cannot hold the training workspace of even 64 rays x {S} samples "
+                f"({per_point / 1e3:.0f} KB per point)")
+        return c
+
     # ---- reference API: rendering ------------------------------------------------------------------------------------
     def forward(self, rays, **kwargs):
         return self.render_rays(rays, **kwargs)
 
+    @_on_device
     def sample_z(self, rays, iter_step=0, perturb_overwrite=None, u_perturb=None):
         """Sampling stage of render_rays (endosurf.py:63-110): coarse samples + SDF-guided up-sampling, no grad. -> z_vals [N, S]"""
         rays = self._rays32(rays)
@@ -401,6 +588,74 @@ class EndoSurfRenderer(nn.Module):
             return self.engine.sample_z(rays, u, weff.detach(), packed, self.use_deform, self.n_samples, self.n_importance,
                                         self.up_sample_steps, upsample)
 
+    def _rays_from(self, rays_o, rays_d, time=None):
+        n = rays_o.shape[0]
+        t = time.reshape(n, 1) if time is not None else torch.zeros(n, 1, device=self.device)
+        return torch.cat([rays_o, rays_d, torch.zeros(n, 2, device=self.device), t], -1).detach().to(torch.float32).contiguous()
+
+    @_on_device
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        """reference up_sample (endosurf.py:221-266) + sample_pdf(det=True) (utils.py:160-191): ``n_importance`` new depths per
+        ray from the section weights at a fixed ``inv_s``.  One launch (es_upsample_step).  -> z_samples [N, n_importance]"""
+        N, n = z_vals.shape
+        eng = self.engine
+        rays = self._rays_from(rays_o, rays_d)
+        z = z_vals.detach().to(torch.float32).contiguous()
+        sd = sdf.detach().to(torch.float32).reshape(N, n).contiguous()
+        S = n + int(n_importance)
+        z_new, z_out, src = eng.empty(N, int(n_importance)), eng.empty(N, S), eng.empty(N, S, dtype=torch.int32)
+        _lib.check(eng.lib.es_upsample_step(_lib.ptr(rays), _lib.ptr(z), n, _lib.ptr(sd), n, N, n, int(n_importance), float(inv_s),
+                                            _lib.ptr(z_new), _lib.ptr(z_out), S, _lib.ptr(src), eng.st()), "es_upsample_step")
+        return z_new
+
+    @_on_device
+    def cat_z_vals(self, rays_o, rays_d, time, z_vals, new_z_vals, sdf, last=False):
+        """reference cat_z_vals (endosurf.py:268-287): merge the new depths into the sorted ones (ties: old sample first; the
+        reference's torch.sort leaves their order unspecified) and, unless ``last``, query the SDF at the new depths
+        (es_query_sdf) and permute it alongside (es_merge_sdf).  -> (z_vals [N, n+m], sdf [N, n+m]; ``sdf`` unchanged if last)"""
+        N, n = z_vals.shape
+        m = new_z_vals.shape[1]
+        eng = self.engine
+        z_new = new_z_vals.detach().to(torch.float32).contiguous()
+        z_cat = torch.cat([z_vals.detach().to(torch.float32), z_new], dim=-1)
+        z_sorted, index = torch.sort(z_cat, dim=-1, stable=True)
+        if last:
+            return z_sorted, sdf
+        rays = self._rays_from(rays_o, rays_d, time)
+        weff, packed = self._weights()
+        with torch.no_grad():
+            sdf_new = eng.query_sdf(eng.points(rays=rays, z=z_new, n_per_ray=m, ldz=m), weff.detach(), packed, self.use_deform)
+        sd = sdf.detach().to(torch.float32).reshape(N, n).contiguous()
+        src = index.to(torch.int32).contiguous()
+        out = eng.empty(N, n + m)
+        _lib.check(eng.lib.es_merge_sdf(_lib.ptr(sd), n, _lib.ptr(sdf_new), m, _lib.ptr(src), n + m, N, n, _lib.ptr(out), eng.st()), "es_merge_sdf")
+        return z_sorted, out
+
+    @_on_device
+    def secant(self, f_low, f_high, d_low, d_high, n_secant_steps, rays, tau, max_points=64000):
+        """reference secant (endosurf.py:422-449) for the bracket [d_low, d_high] of every ray in ``rays`` [M,9]: n_secant_steps
+        dependent (points -> SDF query -> bracket update) rounds on the device.  Like the reference, the four bracket tensors are
+        updated in place; -> d_pred [M]."""
+        M = rays.shape[0]
+        eng = self.engine
+        if M == 0:
+            return torch.zeros(0, device=self.device)
+        rays32 = self._rays32(rays)
+        weff, packed = self._weights()
+        f = lambda a: a.detach().to(torch.float32).reshape(M)
+        state = torch.stack([f(d_low), f(f_low), f(d_high), f(f_high)], -1).contiguous()
+        d_pred = (-state[:, 1] * (state[:, 2] - state[:, 0]) / (state[:, 3] - state[:, 1]) + state[:, 0]).contiguous()
+        x, t = eng.empty(M, 3), eng.empty(M)
+        with torch.no_grad():
+            for _ in range(int(n_secant_steps)):
+                _lib.check(eng.lib.es_secant_points(_lib.ptr(rays32), _lib.ptr(d_pred), M, _lib.ptr(x), _lib.ptr(t), eng.st()), "es_secant_points")
+                f_mid = eng.query_sdf(eng.points(x=x, t=t), weff.detach(), packed, self.use_deform)
+                _lib.check(eng.lib.es_secant_update(_lib.ptr(f_mid), M, float(tau), _lib.ptr(state), _lib.ptr(d_pred), eng.st()), "es_secant_update")
+            for k, dst in enumerate((d_low, f_low, d_high, f_high)):
+                dst.copy_(state[:, k].reshape(dst.shape).to(dst.dtype))
+        return d_pred
+
+    @_on_device
     def render_rays(self, rays, iter_step=0, perturb_overwrite=None, eval=False, u_perturb=None, aux_points=None, z_vals=None, **kwargs):
         """reference render_rays (endosurf.py:60-132).  ``u_perturb`` ([N] or [N,1] uniform draws) may be supplied to
         make the stratified jitter reproducible; otherwise it is drawn with torch.rand on the device like the reference.
@@ -427,6 +682,7 @@ class EndoSurfRenderer(nn.Module):
             "s_val": ret["s_val"].reshape(1, 1).expand(n_rays, 1),      # mean over the samples of one shared value (endosurf.py:131)
         }
 
+    @_on_device
     def render_core(self, rays_o, rays_d, time, z_vals, sample_dist, cos_anneal_ratio=0.0, eval=False, _rays=None, _aux=None):
         """reference render_core (endosurf.py:134-213)."""
         if _rays is None:
@@ -439,8 +695,10 @@ class EndoSurfRenderer(nn.Module):
         if _aux is not None:
             aux_x = _aux[0].detach().to(torch.float32).contiguous()
             aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
+        flags = self._flags(weff)
         color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go = _RenderFn.apply(
-            weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), self._flags(weff), aux_x, aux_t)
+            weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), flags, aux_x, aux_t,
+            self._chunk_rays(z.shape[0], z.shape[1], flags))
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
         s_val = _SValFn.apply(var, self.engine)                 # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
@@ -448,13 +706,18 @@ class EndoSurfRenderer(nn.Module):
                 "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
 
     # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
-    def _point_eval(self, x, t, dirs=None):
+    def _point_eval(self, x, t, dirs=None, canonical=False):
+        """(sdf [M,1], g_o [M,3]) at explicit points; ``canonical``: x is a canonical-space point (SDF network only, g_o = g_c)."""
         weff, packed = self._weights()
         pts = self.engine.points(x=x.detach().to(torch.float32).contiguous(), t=t.detach().to(torch.float32).reshape(-1).contiguous(),
                                  dirs=dirs)
-        sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, self._flags(weff))
+        flags = self._flags(weff)
+        if canonical:
+            flags &= ~_lib.PF_DEFORM
+        sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, flags)
         return sdf, g_o
 
+    @_on_device
     def errorondepth(self, rays, d_gt, mask, iter_step=0):
         rays = self._rays32(rays)
         pts, time = self._eod_points(rays, d_gt)
@@ -479,6 +742,7 @@ class EndoSurfRenderer(nn.Module):
         angle_error = relu_cos.abs().sum() / denom          # not masked, like the reference (endosurf.py:315)
         return sdf_error, angle_error, inside_masksphere
 
+    @_on_device
     def ray_marching(self, rays, tau=0.0, n_steps=(128, 129), n_secant_steps=8, max_points=64000):
         """reference ray_marching + secant (endosurf.py:344-449); n_steps is always 128 there. Fixed shape on device."""
         rays = self._rays32(rays)
@@ -486,6 +750,7 @@ class EndoSurfRenderer(nn.Module):
         with torch.no_grad():
             return self.engine.ray_marching(rays, weff.detach(), packed, self.use_deform, int(n_steps[0]), n_secant_steps, tau)
 
+    @_on_device
     def surface_neighbour_error(self, rays, mask, iter_step=0, neighbour_rad=0.05, u_neigh=None):
         """reference surface_neighbour_error (endosurf.py:319-342), evaluated at fixed shape (all rays, masked mean)
         so that no host synchronisation is needed; returns a 0-d tensor (0 when no ray is valid)."""
@@ -525,7 +790,7 @@ class EndoSurfRenderer(nn.Module):
         x, t = self.engine.empty(3 * N, 3), self.engine.empty(3 * N)
         valid = self.engine.empty(N, dtype=torch.bool)
         _lib.check(self.engine.lib.es_train_aux_points(_lib.ptr(rays), _lib.ptr(f(depth_gt)), _lib.ptr(f(mask)), _lib.ptr(f(d_i)), _lib.ptr(u),
-                                                       float(neighbour_rad), N, _lib.ptr(x), _lib.ptr(t), _lib.ptr(valid), _lib.stream_ptr()),
+                                                       float(neighbour_rad), N, _lib.ptr(x), _lib.ptr(t), _lib.ptr(valid), self.engine.st()),
                    "es_train_aux_points")
         return x, t, valid
 
@@ -536,6 +801,7 @@ class EndoSurfRenderer(nn.Module):
         return diff.sum() / torch.clamp(valid.sum() * 3, min=1).to(self.dtype)
 
     # ---- full-frame rendering (the reference's eval loop, trainer_endosurf.py:221-240) -----------------------------------
+    @_on_device
     def render_frames(self, rays, iter_step=0, ray_chunk=2048, perturb_overwrite=None, use_graph=True):
         """Volume-render ``rays`` [..., 9] in fixed chunks of ``ray_chunk`` rays (cfg ``train.eval.ray_chunk``), no grad:
         returns dict(color [n,3], depth [n,1], normal [n,3] = sum_s g_o * w) on the device — what the reference's eval /
@@ -597,6 +863,7 @@ class EndoSurfRenderer(nn.Module):
             pctx = self.engine.point_forward(pts, weff.detach(), packed, (_lib.PF_DEFORM if self.use_deform else 0) | _lib.PF_COLOR)
             return pctx.view("rgb").clone(), pctx.view("go").clone()
 
+    @_on_device
     def renderonpts(self, pts, dirs, ts, net_chunk=80000, cpu=True):
         """Surface rendering at given points (reference endosurf.py:502-521): colour (torch, on device) and unit normal
         (numpy if ``cpu`` else torch), shaped like ``pts``.  ``ts``: [M,1] or the shared-time form [1].  ``net_chunk`` bounds
@@ -614,6 +881,7 @@ class EndoSurfRenderer(nn.Module):
         normal = torch.cat(normals, 0).reshape(*sh, 3)
         return color, (normal.cpu().numpy() if cpu else normal)
 
+    @_on_device
     def renderondepth(self, rays, depth):
         """Surface rendering at a given depth per ray (reference endosurf.py:450-488): (colour [N,3], g_o [N,3], d_out [N,1]);
         rays with depth <= 0 or +inf give zeros, +inf depths are replaced by the far sphere intersection in d_out.
@@ -633,6 +901,7 @@ class EndoSurfRenderer(nn.Module):
             z = torch.zeros_like(rgb)
             return torch.where(valid, rgb, z), torch.where(valid, g, z), d_out
 
+    @_on_device
     def extract_fields(self, bound_min, bound_max, resolution, t, net_chunk=1 << 22):
         """SDF on a resolution^3 linspace grid at time ``t`` (reference extract_fields, utils.py:139-157, with the query of
         extract_observation_geometry): the grid coordinates are generated on the device, sampled by the fused query kernel in
@@ -650,6 +919,7 @@ class EndoSurfRenderer(nn.Module):
             u[i * R * R:(i + per_x) * R * R] = self.sdf_observed(pts, tt).reshape(-1)
         return u.reshape(R, R, R).cpu().numpy()
 
+    @_on_device
     def extract_observation_geometry(self, t, bound_min, bound_max, resolution, threshold=0.0, net_chunk=1 << 22, cpu=True):
         """(vertices, triangles) of the observed-space surface at time t (reference endosurf.py:490-500 + extract_geometry,
         utils.py:128-136).  Field sampling runs on the GPU; the iso-surface extractor is PyMCubes when installed (as in the
@@ -662,6 +932,7 @@ class EndoSurfRenderer(nn.Module):
         vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
         return vertices, triangles
 
+    @_on_device
     def sdf_observed(self, pts, t):
         """get_sdf_from_observed_space (endosurf.py:570-579) for [M,3] points and [M] / scalar time, no grad."""
         weff, packed = self._weights()

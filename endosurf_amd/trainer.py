@@ -95,7 +95,7 @@ class _LossFn(torch.autograd.Function):
         a.w_color, a.w_depth, a.w_sdf, a.w_angle, a.w_eik, a.w_sn = (float(w[k]) for k in ("color", "depth", "sdf", "angle", "eikonal", "surf_neig"))
         for name, t in zip(("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go"), [terms] + grads):
             setattr(a, name, _lib.ptr(t))
-        _lib.check(eng.lib.es_train_loss(C.byref(a), _lib.stream_ptr()), "es_train_loss")
+        _lib.check(eng.lib.es_train_loss(C.byref(a), eng.st()), "es_train_loss")
         ctx.set_materialize_grads(False)
         ctx.grads = grads
         ctx.eik_shape = eik.shape
@@ -208,6 +208,7 @@ class FlatAdam:
         from . import _lib
         g = self.flat_grad() if grad is None else grad
         gv = None if (variance_in_grad or self._var.grad is None) else self._var.grad
+        frozen = [(p, p.detach().clone()) for p in self._all if not p.requires_grad]      # the launch updates the whole buffer
         self.step_count += 1
         pg = self.param_groups[0]
         b1, b2 = pg["betas"]
@@ -215,16 +216,76 @@ class FlatAdam:
         bc2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
         _lib.check(self.eng.lib.es_adam_step(_lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                              self.flat.numel(), b1, b2, pg["eps"], step_size, bc2_sqrt, float(grad_scale),
-                                             _lib.ptr(gv) if gv is not None else None, self._var_off, _lib.stream_ptr()), "es_adam_step")
+                                             _lib.ptr(gv) if gv is not None else None, self._var_off, self.eng.st()), "es_adam_step")
+        if frozen:
+            with torch.no_grad():
+                torch._foreach_copy_([p for p, _ in frozen], [v for _, v in frozen])
         self.model._epoch += 1            # parameters changed behind torch's version counters: invalidate the packed weights
 
+    # ---- checkpoint format: torch.optim.Adam's own (what the reference stores as ckpt["optimizer"], trainer_endosurf.py:76-92) ----
+    def _train_param_slots(self):
+        """[(flat offset, numel, shape)] in the reference optimiser's parameter order = get_train_params() order
+        (trainer_endosurf.py:60-71: deform, sdf, colour networks layer by layer (bias, weight_g, weight_v), then the variance)."""
+        groups = self.model.get_train_params()
+        byid = {id(p): (off, p) for off, p in self._named}
+        byid[id(self._var)] = (self._var_off, self._var)
+        out = []
+        for key in groups:
+            for p in groups[key]:
+                off, q = byid[id(p)]
+                out.append((off, q.numel(), tuple(q.shape)))
+        return out
+
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), param_groups=self.param_groups)
+        """A torch.optim.Adam state_dict ({"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups": [...]}) that the reference
+        trainer's ``optimizer.load_state_dict`` accepts: the flat moment buffers are scattered to per-parameter tensors."""
+        import copy
+        slots = self._train_param_slots()
+        state = {}
+        if self.step_count > 0:
+            for i, (off, n, shape) in enumerate(slots):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[off:off + n].view(shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[off:off + n].view(shape).clone())
+        pg = copy.deepcopy(self.param_groups[0])
+        group = dict(lr=pg["lr"], betas=tuple(pg["betas"]), eps=pg["eps"], weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(slots))))
+        group.update({k: v for k, v in pg.items() if k not in group})
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        """Accepts a torch.optim.Adam state_dict (reference checkpoints: ckpt["optimizer"]) or the flat round-1 format
+        {"step", "exp_avg", "exp_avg_sq", "param_groups"}."""
+        import copy
+        if "state" not in sd:           # flat format
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups = [dict(copy.deepcopy(g)) for g in sd["param_groups"]]
+            return
+        slots = self._train_param_slots()
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(slots):
+            raise ValueError(f"optimizer state_dict has {[len(g['params']) for g in groups]} parameters per group; this model has one group "
+                             f"of {len(slots)} (use_deform = {self.model.use_deform})")
+        g = groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam implements the reference's plain Adam (no weight decay / amsgrad / maximize)")
+        state = {int(k): v for k, v in sd["state"].items()}
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for pos, pid in enumerate(g["params"]):
+            st = state.get(int(pid))
+            if st is None:
+                continue
+            off, n, shape = slots[pos]
+            if tuple(st["exp_avg"].shape) != shape:
+                raise ValueError(f"optimizer state of parameter {pos} has shape {tuple(st['exp_avg'].shape)}, expected {shape}")
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); FlatAdam keeps one step count")
+        self.step_count = steps.pop() if steps else 0
+        self.param_groups = [dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])]
 
 
 class Trainer:
@@ -259,6 +320,24 @@ class Trainer:
         return lr
 
     def train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        with torch.cuda.device(self.renderer.device):
+            return self._train_step(batch, global_step, u_perturb, u_neigh)
+
+    def save_checkpoint(self, global_step: int):
+        """The reference's ckpt.tar dictionary (trainer_endosurf.py:85-92): the four network state_dicts, "n_iter", "optimizer"."""
+        ckpt = self.renderer.save_checkpoint()
+        ckpt["n_iter"] = int(global_step)
+        ckpt["optimizer"] = self.optimizer.state_dict()
+        return ckpt
+
+    def load_checkpoint(self, ckpt) -> int:
+        """Resume from a (reference or own) ckpt dictionary (trainer_endosurf.py:76-83); returns the next iteration."""
+        self.renderer.load_checkpoint(ckpt)
+        if "optimizer" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        return int(ckpt.get("n_iter", 0)) + 1
+
+    def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
         self.optimizer.zero_grad(set_to_none=True)
         loss, terms, ret = self.loss_fn(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
         loss.backward()

@@ -40,9 +40,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_layout_queries_match_reference_shapes(lib):
-    from endosurf_amd import params
+    from endosurf_amd import _lib, params
     import weightgen
-    assert lib.es_abi_version() == 1
+    assert lib.es_abi_version() == _lib.ABI_VERSION
     assert lib.es_param_floats() == 1654951            # reference parameter count
     lay = params.layout()
     state = weightgen.make_state(1, "init", True)

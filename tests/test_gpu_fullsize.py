@@ -103,19 +103,31 @@ def test_config3_2048_rays_128_samples_eikonal_and_step():
     cfg3 = dict(RENDER_CFG, n_samples=64, n_importance=64)
     r = renderer_for(31, "trained", True, render_cfg=cfg3)
     b = SyntheticScene("cuda", seed=15).batch(2048)
+    # widen the field of view of half the rays: d / d.z then overshoots the unit sphere (endosurf.py:66 quirk), so that many samples
+    # fall in the shell 1.0 <= |p| < 1.2 and beyond 1.2 -- otherwise the eikonal mask radius could not be told apart
+    dd = b["rays"][1024:, 3:6].clone()
+    dd[:, :2] *= 1.8
+    b["rays"][1024:, 3:6] = dd / dd.norm(dim=-1, keepdim=True)
     with torch.no_grad():
         out = r(b["rays"], iter_step=20000, perturb_overwrite=False)
     assert tuple(out["weights"].shape) == (2048, 128) and tuple(out["gradients_o"].shape) == (2048, 128, 3)
-    # eikonal term = masked mean of (|g_o| - 1)^2 over the samples inside the unit sphere (endosurf.py:199-203)
+    # eikonal term = masked mean of (|g_o| - 1)^2 over the samples with |p| < 1.2 (relax_inside_sphere, endosurf.py:191-203)
     g = out["gradients_o"]
     z = r.sample_z(b["rays"], 20000, perturb_overwrite=False)
     sd = 2.0 / 64
     mid = z + torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sd)], -1) * 0.5
     d = b["rays"][:, 3:6]
     pts = b["rays"][:, None, :3] + (d / (d[:, 2:] + 1e-6))[:, None, :] * mid[..., None]
-    inside = (pts.norm(dim=-1) < 1.0).float()
-    eik = (((g.norm(dim=-1) - 1.0) ** 2) * inside).sum() / (inside.sum() + 1e-6)
-    assert abs(float(eik) - float(out["gradient_o_error"])) < 1e-4 * max(1.0, float(eik))
+    err = (g.norm(dim=-1) - 1.0) ** 2
+
+    def eik_for(radius):
+        inside = (pts.norm(dim=-1) < radius).float()
+        return float((err * inside).sum() / (inside.sum() + 1e-6)), float(inside.mean())
+    eik, frac = eik_for(1.2)
+    eik_wrong, frac_wrong = eik_for(1.0)
+    assert 0.05 < frac < 0.999 and frac - frac_wrong > 0.02, (frac, frac_wrong)      # the shell is populated and some samples lie outside
+    assert abs(eik_wrong - eik) > 1e-3 * max(1.0, eik), "test input cannot tell the mask radius apart"
+    assert abs(eik - float(out["gradient_o_error"])) < 1e-4 * max(1.0, eik)
     tr = Trainer(r, warm_up_end=1)
     loss, terms, _ = tr.train_step(b, 20000)
     assert np.isfinite(float(loss)) and bool(torch.isfinite(r.model._flat).all())

@@ -1,0 +1,131 @@
+"""GPU parity of the drop-in's PUBLIC reference methods that round 1 lacked: EndoSurfRenderer.up_sample /
+cat_z_vals / secant (endosurf.py:221-287, 422-449) and the EndoSurfNet query surface (endosurf.py:570-689), against vectors the
+reference itself produced (tests/golden/*.npz, tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import renderer_for_case
+from oracle_util import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def qdiff(a, b, q):
+    return float(np.quantile(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)), q))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_up_sample_and_cat_z_vals_follow_reference_trace(name):
+    """Drive up_sample + cat_z_vals exactly as tools/make_golden.py:z_trace drives the reference's and compare every
+    intermediate z / sdf array (budget: 3x the reference's own fp32-vs-fp64 difference)."""
+    c = load_case(name)
+    r = renderer_for_case(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    o, d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+    z = torch.from_numpy(c["z_trace/0"]).cuda()
+    sdf = r.model.get_sdf_from_observed_space(
+        (o[:, None, :] + (d / (d[:, 2:] + 1e-6))[:, None, :] * z[:, :, None]).reshape(-1, 3),
+        time[:, None, None].expand(z.shape[0], z.shape[1], 1).reshape(-1, 1)).reshape(z.shape)
+    assert np.max(np.abs(sdf.cpu().numpy() - c["sdf_trace64/0"])) < 3 * np.max(np.abs(c["sdf_trace/0"] - c["sdf_trace64/0"])) + 1e-5
+    for i in range(r.up_sample_steps):
+        new_z = r.up_sample(o, d, z, sdf, r.n_importance // r.up_sample_steps, 64 * 2 ** i)
+        assert tuple(new_z.shape) == (z.shape[0], r.n_importance // r.up_sample_steps)
+        last = i + 1 == r.up_sample_steps
+        z, sdf = r.cat_z_vals(o, d, time, z, new_z, sdf, last=last)
+        zt = z.cpu().numpy()
+        ref64, ref32 = c[f"z_trace64/{i + 1}"], c[f"z_trace/{i + 1}"]
+        assert zt.shape == ref64.shape and np.all(np.diff(zt, axis=1) >= 0)
+        assert qdiff(zt, ref64, 0.99) < 3 * qdiff(ref32, ref64, 0.99) + 2e-6, i
+        assert np.max(np.abs(zt - ref64)) < 3 * np.max(np.abs(ref32 - ref64)) + 1e-4, i
+        if not last:
+            s64, s32 = c[f"sdf_trace64/{i + 1}"], c[f"sdf_trace/{i + 1}"]
+            st = sdf.cpu().numpy()
+            assert st.shape == s64.shape
+            assert qdiff(st, s64, 0.99) < 3 * qdiff(s32, s64, 0.99) + 1e-5, i
+    # the public methods give what the fused sampling stage gives
+    u = torch.from_numpy(c["u_perturb"]).cuda() if "u_perturb" in c else None
+    zs = r.sample_z(rays, int(c["meta/iter_step"]), perturb_overwrite=u is not None, u_perturb=u)
+    assert np.max(np.abs(zs.cpu().numpy() - z.cpu().numpy())) < 3 * np.max(np.abs(c["z_trace/4"] - c["z_trace64/4"])) + 1e-4
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_public_secant_matches_ray_marching(name):
+    """ray_marching == (first sign change) + secant: feed the public secant the bracket the reference's ray_marching would pass
+    it (endosurf.py:399-413) and compare with march64/d_i."""
+    c = load_case(name)
+    r = renderer_for_case(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    N, n_steps = rays.shape[0], 128
+    dprop = r.engine.empty(N, n_steps)
+    near, far = r.engine.ray_setup(rays, None, n_steps, 0.0, 1, dprop, want_bounds=True)
+    o, d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
+    pts = (o[:, None, :] + (d / (d[:, 2:] + 1e-6))[:, None, :] * dprop[:, :, None]).reshape(-1, 3)
+    val = -r.model.get_sdf_from_observed_space(pts, time[:, None].expand(N, n_steps).reshape(-1)).reshape(N, n_steps)
+    # first sign change, as the reference finds it
+    sign = torch.cat([torch.sign(val[:, :-1] * val[:, 1:]), torch.ones(N, 1, device="cuda")], -1)
+    cost = sign * torch.arange(n_steps, 0, -1, device="cuda").float()
+    values, idx = torch.min(cost, -1)
+    ar = torch.arange(N, device="cuda")
+    mask = (values < 0) & (val[ar, idx] < 0) & (val[:, 0] < 0)
+    idx2 = torch.clamp(idx + 1, max=n_steps - 1)
+    d_low, f_low, d_high, f_high = dprop[ar, idx][mask], val[ar, idx][mask], dprop[ar, idx2][mask], val[ar, idx2][mask]
+    d_pred = r.secant(f_low, f_high, d_low, d_high, 8, rays[mask], 0.0, 64000)
+    ref64, ref32 = c["march64/d_i"][:, 0], c["march/d_i"][:, 0]
+    fin = np.isfinite(ref64) & (ref64 != 0)
+    assert np.array_equal(mask.cpu().numpy(), fin)
+    budget = 3 * np.max(np.abs(ref32[fin] - ref64[fin])) + 2e-5
+    assert np.max(np.abs(d_pred.cpu().numpy() - ref64[fin])) < budget
+    # and the fused device-side ray_marching agrees with it
+    d_i = r.ray_marching(rays).cpu().numpy()[:, 0]
+    assert np.max(np.abs(d_i[fin] - d_pred.cpu().numpy())) < 2e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_model_query_surface(name):
+    """renderer.model.{get_sdf_from_observed_space, get_sdf_grad_from_observed_space, get_sdf_grad_from_canonical_space,
+    get_deform_grad_from_observed_space, forward} against the reference's pt64/* vectors."""
+    c = load_case(name)
+    r = renderer_for_case(c)
+    m = r.model
+    x, d, t = (torch.from_numpy(c[f"pt/{k}"]).cuda() for k in ("x", "d", "t"))
+    g = lambda a: a.detach().cpu().numpy()
+    with torch.no_grad():
+        assert np.max(np.abs(g(m.get_sdf_from_observed_space(x, t)) - c["pt64/sdf_observed"])) < 1e-5
+        assert np.max(np.abs(g(m.get_sdf_grad_from_observed_space(x, t)) - c["pt64/g_o"])) < 1e-4
+        J = g(m.get_deform_grad_from_observed_space(x, t))
+        assert J.shape == c["pt64/J"].shape == (x.shape[0], 3, 3)
+        assert np.max(np.abs(J - c["pt64/J"])) < 1e-4
+        x_c = x + torch.from_numpy(c["pt64/deform"]).cuda() if r.use_deform else x
+        assert np.max(np.abs(g(m.get_sdf_grad_from_canonical_space(x_c)) - c["pt64/g_c"])) < 1e-4
+        out = g(m.forward(torch.cat([x, d, t], -1)))
+        assert out.shape == (x.shape[0], 4)
+        assert np.max(np.abs(out[:, :1] - c["pt64/sdf_observed"])) < 1e-5
+        assert np.max(np.abs(out[:, 1:] - c["pt64/rgb"])) < 5e-5
+    # grad mode on: the same values, differentiable w.r.t. the parameters (hand-written backward)
+    for p in r.parameters():
+        p.grad = None
+    sdf = m.get_sdf_from_observed_space(x, t)
+    assert sdf.requires_grad and np.max(np.abs(g(sdf) - c["pt64/sdf_observed"])) < 1e-5
+    (sdf.sum() + m.forward(torch.cat([x, d, t], -1))[:, 1:].sum()).backward()
+    gn = dict(r.named_parameters())["model.sdf_network.net.2.weight_v"].grad
+    assert gn is not None and float(gn.norm()) > 0
+
+
+def test_parameter_rebinding_is_detected():
+    """Anything that gives a parameter its own storage (``p.data = ...`` loaders) is folded back into the flat buffer the kernels
+    read, and ``.to()`` moves the flat buffer itself (stale-weights hazard)."""
+    c = load_case("trained_deform")
+    r = renderer_for_case(c)
+    x, t = torch.from_numpy(c["pt/x"]).cuda(), torch.from_numpy(c["pt/t"]).cuda()
+    with torch.no_grad():
+        s0 = r.model.get_sdf_from_observed_space(x, t).clone()
+        p = r.model.sdf_network.net[8].bias
+        p.data = p.data.clone() + 0.25          # re-bound storage: no longer a view of model._flat
+        s1 = r.model.get_sdf_from_observed_space(x, t)
+        assert torch.allclose(s1, s0 + 0.25, atol=1e-5)
+        assert p.data_ptr() == r.model._flat.data_ptr() + 4 * r.model._layout["sdf_network.net.8.bias"][0]
+        r.to("cuda")
+        assert torch.allclose(r.model.get_sdf_from_observed_space(x, t), s1, atol=0)
+        with pytest.raises(TypeError):
+            r.double()

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Train the REFERENCE renderer (CPU, build container only) on the synthetic scene and record the PSNR curve.
 
-    python tools/psnr_reference.py [n_iter] [n_rays]     -> tests/golden/psnr_reference.npz
+    python tools/psnr_reference.py [n_iter] [n_rays] [dtype=float32|float64] [threads] [out name]
+        -> tests/golden/<out name>.npz   (default psnr_reference)
+
+Round 2: the committed curve runs to a PLATEAU (1500 iterations, cosine LR decayed to 5 %), and the same run is repeated
+in fp64 and in fp32 with a different intra-op thread count (another GEMM summation order), so that the reference's OWN
+run-to-run PSNR spread is on record (tests/golden/psnr_reference_fp64.npz, psnr_reference_t3.npz): that spread is the floor
+of any "matched PSNR" tolerance.
 
 The loss arithmetic / Adam / LR schedule of trainer_endosurf.py:94-203 are restated here (the reference trainer cannot be
 imported offline: wandb/cv2/open3d/... are missing); the renderer itself is the reference's, unmodified."""
@@ -22,14 +28,26 @@ import weightgen
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dtype = getattr(torch, sys.argv[3]) if len(sys.argv) > 3 else torch.float32
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+out_name = sys.argv[5] if len(sys.argv) > 5 else "psnr_reference"
 E = MG.import_reference()
-torch.set_num_threads(8)
+torch.set_num_threads(threads)
+torch.set_default_dtype(dtype)
 cfg = MG.load_cfg(True)
 state = weightgen.make_state(7, "init", True)
 r = MG.build_ref(E, cfg, state)
+if dtype == torch.float64:
+    r = r.double()
+    r.dtype = torch.float64
 opt = torch.optim.Adam([p for p in r.parameters()], lr=5e-4)
 sched = synth_scene.schedule(11, n_iter, n_rays)
-ev = {k: torch.from_numpy(v) for k, v in synth_scene.eval_batch().items()}
+ev = {k: torch.from_numpy(v).to(dtype) for k, v in synth_scene.eval_batch().items()}
+
+
+def eval_at(it):
+    """every 10 iterations over the first 300 (the steep part), every 50 after that, and the last one"""
+    return it == 1 or (it <= 300 and it % 10 == 0) or it % 50 == 0 or it == n_iter
 
 
 def lr_factor(it, n_total=n_iter, warm=max(n_iter // 10, 1), alpha=0.05):
@@ -46,7 +64,7 @@ def psnr(a, b, m):
 curve, losses = [], []
 t0 = time.time()
 for it in range(1, n_iter + 1):
-    b = {k: torch.from_numpy(v) for k, v in sched[it - 1].items()}
+    b = {k: torch.from_numpy(v).to(dtype) for k, v in sched[it - 1].items()}
     for g in opt.param_groups:
         g["lr"] = 5e-4 * lr_factor(it)
     opt.zero_grad()
@@ -63,12 +81,12 @@ for it in range(1, n_iter + 1):
     loss.backward()
     opt.step()
     losses.append(float(loss))
-    if it % 10 == 0 or it == 1:
+    if eval_at(it):
         with torch.no_grad():
             e = r(ev["rays"], iter_step=it, perturb_overwrite=False)
         curve.append((it, psnr(e["color_map"].numpy(), ev["color"].numpy(), ev["mask"].numpy()),
                       float(((e["depth_map"] - ev["depth"]).abs() * ev["mask"]).sum() / ev["mask"].sum())))
         print(f"it {it:4d} loss {float(loss):.4f} psnr {curve[-1][1]:.3f} depth_l1 {curve[-1][2]:.4f} ({time.time() - t0:.0f}s)", flush=True)
-np.savez(os.path.join(REPO, "tests", "golden", "psnr_reference.npz"), curve=np.array(curve, np.float64), loss=np.array(losses, np.float64),
-         n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11)
+np.savez(os.path.join(REPO, "tests", "golden", out_name + ".npz"), curve=np.array(curve, np.float64), loss=np.array(losses, np.float64),
+         n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11, dtype=str(dtype), threads=threads)
 print("saved")
