@@ -247,8 +247,9 @@ class FlatAdam:
                 state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[off:off + n].view(shape).clone(),
                                 exp_avg_sq=self.exp_avg_sq[off:off + n].view(shape).clone())
         pg = copy.deepcopy(self.param_groups[0])
-        group = dict(lr=pg["lr"], betas=tuple(pg["betas"]), eps=pg["eps"], weight_decay=0, amsgrad=False, maximize=False, foreach=None,
-                     capturable=False, differentiable=False, fused=None, params=list(range(len(slots))))
+        # the param_group keys of the installed torch's own Adam (they differ between torch versions), with this optimiser's values
+        tmpl = torch.optim.Adam([torch.zeros(1)], lr=pg["lr"], betas=tuple(pg["betas"]), eps=pg["eps"]).state_dict()["param_groups"][0]
+        group = dict(tmpl, lr=pg["lr"], betas=tuple(pg["betas"]), eps=pg["eps"], params=list(range(len(slots))))
         group.update({k: v for k, v in pg.items() if k not in group})
         return dict(state=state, param_groups=[group])
 
