@@ -9,6 +9,8 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+import os as _os
+_SCHED = int(_os.environ.get("ES_SCHED", "0"))      # dev switch for stream-schedule experiments; 0 = the measured best
 LOSS_WEIGHTS = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)   # base_pull.yml:23-29
 
 
@@ -44,12 +46,19 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     # on a side stream WHILE the main stream iterates the secant (two throughput-bound kernels would only slow each other)
     main = torch.cuda.current_stream(rays.device)
     side = getattr(renderer, "_side_stream", None)
+    sched = _SCHED
     if side is None:
-        side = renderer._side_stream = torch.cuda.Stream(device=rays.device)
-    ms = renderer._march_begin(rays)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
+        side = renderer._side_stream = torch.cuda.Stream(device=rays.device, priority=-1 if sched & 2 else 0)
+    if sched & 1:       # experiment: the sampling chain starts together with the 128-proposal marching query
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
+        ms = renderer._march_begin(rays)
+    else:
+        ms = renderer._march_begin(rays)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
     d_i = renderer._march_refine(ms)
     aux_x, aux_t, valid_sn = renderer._train_aux_points(rays, depth_gt, mask_gt, d_i, surf_neig_rad, u_neigh)    # one launch
     eod_pts = aux_x[:N]

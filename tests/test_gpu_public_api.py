@@ -132,3 +132,29 @@ def test_parameter_rebinding_is_detected():
         assert torch.allclose(r.model.get_sdf_from_observed_space(x, t), s1, atol=0)
         with pytest.raises(TypeError):
             r.double()
+
+
+def test_surface_neighbour_error_documented_divergences():
+    """Two conscious divergences from endosurf.py:319-342, pinned here so that they cannot drift silently:
+    (1) with no valid ray the reference returns the python float 0.; the drop-in returns a 0-d tensor equal to 0 (fixed shape,
+        no host synchronisation) that still supports ``0.1 * sn`` and ``.backward()`` of a sum containing it;
+    (2) the neighbour offsets: the reference draws rand_like(p_surf[valid]) (n_valid x 3 numbers, the k-th valid ray uses the
+        k-th row); the drop-in draws one row per RAY ([N,3], ray i uses row i).  With explicit ``u_neigh`` [N,3] the value equals the
+        reference's when it is handed u_neigh[valid] (that is how tools/make_golden.py feeds it: sn64/value)."""
+    c = load_case("trained_deform")
+    r = renderer_for_case(c)
+    rays = torch.from_numpy(c["rays"]).cuda()
+    mask = torch.from_numpy(c["target/mask"]).cuda()
+    sn0 = r.surface_neighbour_error(rays, torch.zeros_like(mask), neighbour_rad=0.1)
+    assert torch.is_tensor(sn0) and sn0.dim() == 0 and float(sn0) == 0.0
+    (0.1 * sn0 + sum(p.sum() * 0 for p in r.parameters())).backward()
+    un = torch.from_numpy(c["u_neigh"]).cuda()
+    sn = r.surface_neighbour_error(rays, mask, neighbour_rad=0.1, u_neigh=un)
+    v64, v32 = float(c["sn64/value"]), float(c["sn/value"])
+    assert abs(float(sn) - v64) < 3 * abs(v32 - v64) + 2e-5 * max(1.0, abs(v64))
+    # rows of rays without a valid hit are never consumed: scrambling them changes nothing
+    with torch.no_grad():
+        d_i = r.ray_marching(rays)
+    valid = (torch.isfinite(d_i) & (d_i != 0) & (mask == 1))[:, 0]
+    un2 = torch.where(valid[:, None], un, torch.rand_like(un))
+    assert float(r.surface_neighbour_error(rays, mask, neighbour_rad=0.1, u_neigh=un2)) == float(sn)
