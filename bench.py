@@ -73,7 +73,7 @@ def kernel_macs(name, use_deform):
     (J^T g_c, D) and, in the backward, one tangent sweep (J gbar_o, D); SDF 2S (value + reverse / tangent + reverse), colour C; weight
     gradients the same again; the SDF queries D + S.  Launches whose tiles may exit early are not counted as work."""
     D = MAC_D if use_deform else 0
-    return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
+    return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_query_sdf_x3": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
             "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D,
             "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}.get(name)
 
@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--mode", default=None, choices=["train", "forward", "frame"])
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
+    ap.add_argument("--split-precision", action="store_true",
+                    help="OPT-IN extra line, never the headline: large no-grad SDF queries on the bf16 matrix pipes with exact 3-way operand "
+                         "splitting (csrc/query_x3.hip); everything else stays fp32 MFMA")
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
@@ -228,6 +231,8 @@ def main():
     torch.manual_seed(0)
     net_cfg = dict(NET_CFG, use_deform=cfg["use_deform"])
     renderer = EndoSurfRenderer(render_cfg(cfg), net_cfg, device=dev)
+    if args.split_precision:
+        renderer.engine.split_precision = True
     trainer = Trainer(renderer, data_parallel=world > 1, schedule=args.schedule)
     parallel.broadcast_parameters(trainer.params)
     scene = SyntheticScene(dev, seed=1234 + rank)
@@ -329,10 +334,13 @@ def main():
         out = dict(metric={"train": "training rays/sec (%d rays x %d samples)" % (n_rays, S), "forward": "forward rays/sec (%d rays x %d samples)" % (n_rays, S),
                            "frame": "full-frame render rays/sec (640x512, %d samples, %d-ray chunks)" % (S, args.chunk)}[mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                   scaling="strong" if mode == "frame" else "weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   scaling="strong" if mode == "frame" else "weak", vs_baseline=None,
+                   dtype="f32" if not args.split_precision else "f32 (OPT-IN split precision: large SDF queries as 3 x bf16 planes, 6 partial "
+                                                                "products, fp32 accumulate; not the headline configuration)",
+                   data="synthetic",
                    config=dict(workload="BASELINE config %d: %s nets, %d rays x (%d+%d) samples per GPU, %s" % (
                        args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),
-                       baseline_config=args.config, use_deform=cfg["use_deform"],
+                       baseline_config=args.config, use_deform=cfg["use_deform"], split_precision=bool(args.split_precision),
                        ray_marching="all 128 proposals of every ray (data independent, as the reference)" if mode == "train" else None,
                        with_early_exit=extra, rays_per_gpu=n_rays, samples_per_ray=S, parallelism=f"dp{world}",
                        weights="reference init, torch.manual_seed(0)", algorithmic_gflop_per_ray=algorithmic_gflop_per_ray(cfg)),

@@ -59,6 +59,9 @@ PROTOTYPES = {
     "es_weightnorm_pack": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_weightnorm_backward": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_query_sdf": (C.c_int, [C.POINTER(es_points), _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+    "es_packed_x3_bytes": (C.c_int64, []),
+    "es_pack_x3": (_I, [_P, _P, _I, _P]),
+    "es_query_sdf_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _I, _P]),
     "es_ray_setup": (_I, [_P, _P, _I, _I, _F, _I, _P, _I, _P, _P, _P]),
     "es_upsample_step": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P]),
     "es_merge_sdf": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),

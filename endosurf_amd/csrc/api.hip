@@ -14,6 +14,10 @@ int weightnorm_backward(const float* params, const float* dweff, float* dparams,
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out = 0, const int* ray_done = nullptr);
 int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st);
+size_t packed_x3_bytes();
+int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st);
+int query_sdf_x3(const PointSrc& src, const void* packed_x3, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
+                 const int* ray_done);
 int variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, hipStream_t st);
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
@@ -127,6 +131,19 @@ int es_query_sdf_rays(const es_points* pts, const float* packed, const float* we
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
     ES_REQUIRE(pts->mode == 1 && pts->n_per_ray >= 1 && ld_out >= pts->n_per_ray, "es_query_sdf_rays takes ray samples (mode 1), ld_out >= n_per_ray");
     return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream, ld_out, ray_done);
+}
+int64_t es_packed_x3_bytes(void) { return (int64_t)packed_x3_bytes(); }
+int es_pack_x3(const float* weff, void* packed_x3, int use_deform, void* stream) {
+    ES_REQUIRE(weff && packed_x3, "null buffer");
+    return pack_x3(weff, packed_x3, use_deform, (hipStream_t)stream);
+}
+int es_query_sdf_x3(const es_points* pts, const void* packed_x3, const float* weff, float* sdf_out, int ld_out, const int* ray_done,
+                    int use_deform, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed_x3 && weff && (sdf_out || pts->M == 0), "null buffer");
+    ES_REQUIRE(ld_out == 0 || (pts->mode == 1 && ld_out >= pts->n_per_ray), "ld_out > 0 needs ray samples (mode 1), ld_out >= n_per_ray");
+    ES_REQUIRE(ray_done == nullptr || pts->mode == 1, "ray_done needs ray samples (mode 1)");
+    return query_sdf_x3(to_src(pts), packed_x3, weff, sdf_out, use_deform, (hipStream_t)stream, ld_out, ray_done);
 }
 int es_variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, void* stream) {
     ES_REQUIRE(variance && (s_val || d_var) && (!d_var || d_invs_acc), "es_variance_terms arguments");

@@ -40,6 +40,12 @@ class Engine:
         # (bit-identical results from run to run; a few % slower).  Also settable per renderer: ``renderer.engine.deterministic = True``
         self.deterministic = os.environ.get("ES_DETERMINISTIC", "0") not in ("0", "", "false", "False")
         self._wg_scratch = None
+        # opt-in split-precision mode (csrc/query_x3.hip): the large no-grad SDF queries (coarse samples, ray-marching proposals,
+        # field extraction) run on the bf16 matrix pipes with every fp32 operand split exactly into three bf16 planes (six partial
+        # products, fp32 accumulation): fp32-class accuracy at ~2.7x the fp32 MFMA rate.  NOT the default; also settable per
+        # renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
+        self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
+        self._x3 = None
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -109,8 +115,25 @@ class Engine:
             p._keep = (x, t, dirs)
         return p
 
+    def packed_x3(self, weff, use_deform: bool):
+        """The split-precision packing of ``weff`` (rebuilt when a new effective-weight buffer shows up; the cache keeps the source
+        buffer alive so that its address cannot be recycled for other weights)."""
+        c = self._x3
+        if c is None or c[1] != weff.data_ptr() or c[3] != bool(use_deform):
+            buf = torch.empty(int(self.lib.es_packed_x3_bytes()), device=self.device, dtype=torch.uint8)
+            check(self.lib.es_pack_x3(ptr(weff), ptr(buf), int(use_deform), self.st()), "es_pack_x3")
+            c = self._x3 = (weff.detach(), weff.data_ptr(), buf, bool(use_deform))
+        return c[2]
+
+    def _use_x3(self, M: int) -> bool:
+        return self.split_precision and M > 8192          # small batches are latency-bound: they stay on the 16-point fp32 tiles
+
     def query_sdf(self, pts: es_points, weff, packed, use_deform: bool) -> torch.Tensor:
         out = self.empty(pts.M)
+        if self._use_x3(pts.M):
+            check(self.lib.es_query_sdf_x3(C.byref(pts), ptr(self.packed_x3(weff, use_deform)), ptr(weff), ptr(out), 0, None, int(use_deform),
+                                           self.st()), "es_query_sdf_x3")
+            return out
         check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), self.st()), "es_query_sdf")
         return out
 
@@ -233,8 +256,13 @@ class Engine:
             for b in range(n_steps // B):
                 p = self.points(rays=rays, z=dprop, n_per_ray=B, ldz=n_steps)
                 p.z = C.c_void_p(dprop.data_ptr() + 4 * b * B)
-                check(self.lib.es_query_sdf_rays(C.byref(p), ptr(packed), ptr(weff), C.c_void_p(sdf.data_ptr() + 4 * b * B), n_steps,
-                                                 ptr(done) if b else None, int(use_deform), self.st()), "es_query_sdf_rays")
+                if self._use_x3(p.M):
+                    check(self.lib.es_query_sdf_x3(C.byref(p), ptr(self.packed_x3(weff, use_deform)), ptr(weff),
+                                                   C.c_void_p(sdf.data_ptr() + 4 * b * B), n_steps, ptr(done) if b else None, int(use_deform),
+                                                   self.st()), "es_query_sdf_x3")
+                else:
+                    check(self.lib.es_query_sdf_rays(C.byref(p), ptr(packed), ptr(weff), C.c_void_p(sdf.data_ptr() + 4 * b * B), n_steps,
+                                                     ptr(done) if b else None, int(use_deform), self.st()), "es_query_sdf_rays")
                 if b + 1 < n_steps // B:
                     check(self.lib.es_march_progress(ptr(sdf), N, n_steps, (b + 1) * B, float(tau), ptr(done), self.st()), "es_march_progress")
         else:

@@ -487,6 +487,8 @@ class EndoSurfRenderer(nn.Module):
         self.dtype = torch.float32
         self.net_cfg = net_cfg
         self.engine = Engine(self.device)          # raises if not an AMD GPU / library missing: no fallback
+        if "split_precision" in render_cfg:        # opt-in bf16 x 3 SDF queries (engine.split_precision); default: fp32 MFMA everywhere
+            self.engine.split_precision = bool(render_cfg["split_precision"])
         self.model = EndoSurfNet(net_cfg, self.device)
         self.model._renderer = weakref.ref(self)
         self.model._pack_cache = None
