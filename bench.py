@@ -75,7 +75,8 @@ def kernel_macs(name, use_deform):
     D = MAC_D if use_deform else 0
     return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_query_sdf_x3": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
             "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D,
-            "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C}.get(name)
+            "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C,
+            "k_wgrad_x3[deform]": 3 * MAC_D, "k_wgrad_x3[sdf]": 2 * MAC_S, "k_wgrad_x3[color]": MAC_C}.get(name)
 
 
 def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
@@ -199,8 +200,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
     ap.add_argument("--split-precision", action="store_true",
-                    help="OPT-IN extra line, never the headline: large no-grad SDF queries on the bf16 matrix pipes with exact 3-way operand "
-                         "splitting (csrc/query_x3.hip); everything else stays fp32 MFMA")
+                    help="OPT-IN extra line, never the headline: large no-grad SDF queries and the weight-gradient GEMMs on the bf16 matrix "
+                         "pipes with exact 3-way operand splitting (csrc/query_x3.hip, wgrad.hip); everything else stays fp32 MFMA")
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
@@ -335,8 +336,8 @@ def main():
                            "frame": "full-frame render rays/sec (640x512, %d samples, %d-ray chunks)" % (S, args.chunk)}[mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                    scaling="strong" if mode == "frame" else "weak", vs_baseline=None,
-                   dtype="f32" if not args.split_precision else "f32 (OPT-IN split precision: large SDF queries as 3 x bf16 planes, 6 partial "
-                                                                "products, fp32 accumulate; not the headline configuration)",
+                   dtype="f32" if not args.split_precision else "f32 (OPT-IN split precision: large SDF queries and weight-gradient GEMMs as 3 x bf16 "
+                                                                "planes, 6 partial products, fp32 accumulate; not the headline configuration)",
                    data="synthetic",
                    config=dict(workload="BASELINE config %d: %s nets, %d rays x (%d+%d) samples per GPU, %s" % (
                        args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),

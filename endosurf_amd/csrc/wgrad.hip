@@ -338,6 +338,232 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// OPT-IN split-precision variant (flag PF_X3; csrc/query_x3.hip explains the arithmetic): the same task decomposition, but both
+// operand panels are split EXACTLY into three bf16 planes on their way into LDS and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 (six partial products per tile, fp32 accumulation): ~2.7x the fp32 matrix rate, which turns these GEMMs
+// from MFMA-bound into HBM-bound (each operand element is still read once per task).  A stage = 16 rows = one MFMA k-step.
+// LDS per plane: units of 16 B = 8 consecutive ROWS of one column, [row group (2)][column] -> the A / B fragments (lane = column,
+// 8 rows) are single conflict-free ds_read_b128.  Every thread stages one (row group, column) unit of dA (512 units per stage)
+// and threads 0..255 one unit of X: 8 dword loads (row-major operands, coalesced over columns) or 2 float4 loads (fragment-ordered).
+typedef unsigned wx_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WX_R = 16;
+constexpr int WX_A_PLANE = 2 * 256 * 16;                     // 8 KiB
+constexpr int WX_B_PLANE = 2 * WG_KW * 16;                   // 4 KiB
+constexpr int WX_BUF = 3 * (WX_A_PLANE + WX_B_PLANE);        // 36 KiB per stage buffer
+constexpr int WX_LDS_BYTES = 2 * WX_BUF;                     // 72 KiB, one workgroup (8 waves, <= 256 registers) per CU
+static_assert(WX_LDS_BYTES >= WG_LDS_FLOATS * 4, "the small-layer slices and the bias reduction reuse the buffer as float scratch");
+
+__device__ __forceinline__ unsigned wx_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 8 fp32 values -> three bf16x8 planes with v = h + m + l exactly
+__device__ __forceinline__ void wx_split8(const float (&v)[8], wx_u32x4& h, wx_u32x4& m, wx_u32x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = v[2 * j], x1 = v[2 * j + 1];
+        const unsigned hh = wx_cvt_pk(x0, x1);
+        float r0 = x0 - __uint_as_float(hh << 16), r1 = x1 - __uint_as_float(hh & 0xffff0000u);
+        const unsigned mm = wx_cvt_pk(r0, r1);
+        r0 -= __uint_as_float(mm << 16); r1 -= __uint_as_float(mm & 0xffff0000u);
+        h[j] = hh; m[j] = mm; l[j] = wx_cvt_pk(r0, r1);
+    }
+}
+
+struct WxRegs { float a[8]; float b[8]; };
+
+template <bool AF, bool XF, bool DET>
+__device__ __forceinline__ void wgrad_task_x3(const WgProb& P, int kb, int m0, int m1, unsigned char* lds, float* det_tile, float* det_bias) {
+    constexpr int KW = WG_KW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = w & 3, kh = w >> 2;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int kcol0 = kb * KW;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+
+    f32x16 acc[2][2];
+    acc_zero(acc);
+    // staging roles: A unit (ga, na) for every thread, B unit (gb, kk) for threads 0..255
+    const int ga = tid >> 8, na = tid & 255;
+    const bool has_b = tid < 256;
+    const int gb = (tid >> 7) & 1, kk = tid & 127;
+    const int colB = kcol0 + kk;
+    const bool okB = has_b && (XF || colB < P.ldx);
+    // bias gradient = column sums of dA over the rows r with r % bias_stride == 0 (strides 1, 2 or 4; row groups start at
+    // multiples of 8), taken from the staging registers
+    const bool do_bias = P.bias_out != nullptr && kb == 0;
+    float bsum = 0.f;
+    // fragment-ordered operands: the 8 rows of row group g of a stage are the quads (q = 2j + g, hi = 0 / 1) of the tile
+    auto frag_base = [&](const float* base, int m) {
+        return base + (size_t)(m >> 6) * (64 * 256) + (size_t)((8 * ((m >> 5) & 1) + 2 * ((m >> 4) & 1)) * 256);
+    };
+    const size_t foffA = (size_t)((((na >> 6) * 16 + ((na >> 5) & 1) * 4 + ga) * 64 + (na & 31)) * 4);
+    const int cB = (XF ? colB : 0);
+    const size_t foffB = (size_t)((((cB >> 6) * 16 + ((cB >> 5) & 1) * 4 + gb) * 64 + (cB & 31)) * 4);
+
+    auto gload = [&](WxRegs& R, int m) {
+        if constexpr (AF) {
+            const float* pa = frag_base(P.dA, m) + foffA;
+            const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa));
+            const v4f t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa + 32 * 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { R.a[i] = t0[i]; R.a[4 + i] = t1[i]; }
+        } else {
+            const float* pa = P.dA + (size_t)(m + 8 * ga) * P.lda + na;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) R.a[r] = __builtin_nontemporal_load(pa + (size_t)r * P.lda);
+        }
+        if (okB) {
+            if constexpr (XF) {
+                const float* px = frag_base(P.X, m) + foffB;
+                const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(px));
+                const v4f t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(px + 32 * 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { R.b[i] = t0[i]; R.b[4 + i] = t1[i]; }
+            } else {
+                const float* px = P.X + (size_t)(m + 8 * gb) * P.ldx + colB;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) R.b[r] = __builtin_nontemporal_load(px + (size_t)r * P.ldx);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) R.b[r] = 0.f;
+        }
+    };
+    auto sstore = [&](const WxRegs& R, int buf) {
+        unsigned char* Ab = lds + buf * WX_BUF;
+        unsigned char* Bb = Ab + 3 * WX_A_PLANE;
+        wx_u32x4 h, m, l;
+        wx_split8(R.a, h, m, l);
+        const int oa = (ga * 256 + na) * 16;
+        *reinterpret_cast<wx_u32x4*>(Ab + oa) = h;
+        *reinterpret_cast<wx_u32x4*>(Ab + WX_A_PLANE + oa) = m;
+        *reinterpret_cast<wx_u32x4*>(Ab + 2 * WX_A_PLANE + oa) = l;
+        if (do_bias) {
+            if (P.bias_stride == 1) bsum += ((R.a[0] + R.a[1]) + (R.a[2] + R.a[3])) + ((R.a[4] + R.a[5]) + (R.a[6] + R.a[7]));
+            else if (P.bias_stride == 2) bsum += (R.a[0] + R.a[2]) + (R.a[4] + R.a[6]);
+            else bsum += R.a[0] + R.a[4];
+        }
+        if (has_b) {
+            wx_split8(R.b, h, m, l);
+            const int ob = (gb * KW + kk) * 16;
+            *reinterpret_cast<wx_u32x4*>(Bb + ob) = h;
+            *reinterpret_cast<wx_u32x4*>(Bb + WX_B_PLANE + ob) = m;
+            *reinterpret_cast<wx_u32x4*>(Bb + 2 * WX_B_PLANE + ob) = l;
+        }
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = lds + buf * WX_BUF + (hi * 256 + nb * 64 + lo) * 16;
+        const unsigned char* Bb = lds + buf * WX_BUF + 3 * WX_A_PLANE + (hi * KW + kh * 64 + lo) * 16;
+        wx_u32x4 a[2][3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[t][p] = *reinterpret_cast<const wx_u32x4*>(Ab + p * WX_A_PLANE + t * 32 * 16);
+                b[t][p] = *reinterpret_cast<const wx_u32x4*>(Bb + p * WX_B_PLANE + t * 32 * 16);
+            }
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};       // smallest partial products first
+        // partial product q of all four accumulators before q + 1: dependent MFMAs on one accumulator are 3 issues apart
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+                    acc[t][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wx_bf16x8, a[t][TA[q]]),
+                                                                        __builtin_bit_cast(wx_bf16x8, b[tp][TB[q]]), acc[t][tp], 0, 0, 0);
+    };
+
+    const int nst = (m1 - m0) / WX_R;           // even (chunks are multiples of 64 rows)
+    WxRegs p0, p1;
+    gload(p0, m0);
+    gload(p1, m0 + WX_R);
+    sstore(p0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 2 < nst) gload(p0, m0 + WX_R * (st + 2));
+        compute(0);
+        sstore(p1, 1);
+        __syncthreads();
+        if (st + 3 < nst) gload(p1, m0 + WX_R * (st + 3));
+        compute(1);
+        if (st + 2 < nst) sstore(p0, 0);
+        __syncthreads();
+    }
+    // acc[t][tp][r]: n = nb*64 + 32 t + (r & 3) + 8 (r >> 2) + 4 hi ;  k = kb*128 + kh*64 + 32 tp + lo
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            const int k = kcol0 + kh * 64 + 32 * tp + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb * 64 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if constexpr (DET) det_tile[n * WG_KW + (k - kcol0)] = acc[t][tp][r];
+                else if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
+            }
+        }
+    if (do_bias) {      // the two row groups of a column are summed through LDS (all stages consumed)
+        float* red = reinterpret_cast<float*>(lds);
+        red[ga * 256 + na] = bsum;
+        __syncthreads();
+        if (tid < 256) {
+            const float sum = red[tid] + red[256 + tid];
+            if constexpr (DET) det_bias[tid] = sum;
+            else if (tid < P.N) atomicAdd(P.bias_out + tid, sum);
+        }
+    }
+}
+
+template <int NET, bool DET>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_x3(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wxlds[];
+    float* wlds = reinterpret_cast<float*>(wxlds);
+    const int task = blockIdx.x;
+    auto small_slot = [&](int i) { return DET ? a.det + WG_DET_SMALL_OFF + ((size_t)i * WG_MAX_TASKS + task) * (5 * 256) : nullptr; };
+    const bool small_first = task < a.total_tasks / 2;
+    if (small_first) {
+#pragma unroll 1
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
+        __syncthreads();
+    }
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.nprob; ++i)
+        if (task >= a.p[i].task_begin) pi = i;
+    const WgProb& P = a.p[pi];
+    const int local = task - P.task_begin;
+    const int kblk = (P.K + WG_KW - 1) / WG_KW;
+    int kb, mc;
+    wg_decode(local, kblk, (P.M + a.MC - 1) / a.MC, kb, mc);
+    const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
+    float* dt = DET ? a.det + (size_t)task * WG_DET_TILE : nullptr;
+    float* db = DET ? a.det + WG_DET_BIAS_OFF + (size_t)task * 256 : nullptr;
+    if constexpr (NET == 1) {
+        if (P.a_frag) {
+            if (P.x_frag) wgrad_task_x3<true, true, DET>(P, kb, m0, m1, wxlds, dt, db);
+            else wgrad_task_x3<true, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+        } else {
+            if (P.x_frag) wgrad_task_x3<false, true, DET>(P, kb, m0, m1, wxlds, dt, db);
+            else wgrad_task_x3<false, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+        }
+    } else {
+        wgrad_task_x3<false, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+    }
+    if (!small_first) {
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
+    }
+}
+
 // Deterministic mode, pass `round`: out += sum of the task slots in ascending row-chunk / task order.  blockIdx.y = problem
 // (GEMM problems first, then the small ones); problems of one pass write disjoint outputs.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgArgs a, int round) {
@@ -383,7 +609,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgArgs a, int round) {
 
 static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
 
-static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, int kid, long long rows, float* det, hipStream_t st) {
+static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, int kid_timer, long long rows, float* det, bool x3, hipStream_t st) {
+    const int kid = kid_timer == KID_WGRAD_D_X3 ? KID_WGRAD_D : (kid_timer == KID_WGRAD_S_X3 ? KID_WGRAD_S : (kid_timer == KID_WGRAD_C_X3 ? KID_WGRAD_C : kid_timer));
     static DeviceOnce attr_done;
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_wgrad<0, false>, WG_LDS_FLOATS * 4)) return e;
@@ -392,6 +619,12 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
         if (int e = allow_big_lds(k_wgrad<0, true>, WG_LDS_FLOATS * 4)) return e;
         if (int e = allow_big_lds(k_wgrad<1, true>, WG_LDS_FLOATS * 4)) return e;
         if (int e = allow_big_lds(k_wgrad<2, true>, WG_LDS_FLOATS * 4)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<0, false>, WX_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<1, false>, WX_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<2, false>, WX_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<0, true>, WX_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<1, true>, WX_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_wgrad_x3<2, true>, WX_LDS_BYTES)) return e;
         attr_done.done();
     }
     if (nprob == 0) return ST_OK;
@@ -406,8 +639,9 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
     };
     ES_REQUIRE(nsmall <= WG_MAX_SMALL, "too many small weight-gradient problems in one group");
     int MC = 128;
-    while (MC < 65536 && count(MC) > WG_MAX_TASKS) MC += 64;
-    ES_REQUIRE(count(MC) <= WG_MAX_TASKS, "weight-gradient group does not fit one round of workgroup slots");
+    const int slots = x3 ? WG_MAX_TASKS / 2 : WG_MAX_TASKS;       // the split-precision kernel runs one workgroup per CU
+    while (MC < 65536 && count(MC) > slots) MC += 64;
+    ES_REQUIRE(count(MC) <= slots, "weight-gradient group does not fit one round of workgroup slots");
     WgArgs a;
     a.det = det;
     int total = 0, max_round = 0;
@@ -435,7 +669,24 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
         a.s[i] = small[i];
     }
     const dim3 grid(total);
-    ScopedTimer tm(kid, rows, st);
+    ScopedTimer tm(kid_timer, rows, st);
+    if (x3) {
+        auto reduce = [&]() {
+            for (int r = 0; det && r <= max_round; ++r)
+                hipLaunchKernelGGL(k_wgrad_reduce, dim3(32, nprob + nsmall), dim3(256), 0, st, a, r);
+        };
+        if (det) {
+            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((k_wgrad_x3<2, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+        } else {
+            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((k_wgrad_x3<2, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+        }
+        reduce();
+        return ST_OK;
+    }
     if (det) {
         if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad<0, true>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
         else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad<1, true>), grid, dim3(WG_THREADS), WG_LDS_FLOATS * 4, st, a);
@@ -456,6 +707,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
     if (M <= 0) return ST_OK;
     const WsLayout L = ws_layout(M, flags);
     const Tabs tb = make_tabs();
+    const bool x3 = flags & PF_X3;
     const int Mp = L.Mp;
     const int Mc = (flags & PF_COLOR) ? round_up64(m_color > 0 ? m_color : M) : 0;   // rows that went through the colour network
     const size_t t256 = (size_t)Mp * 256;
@@ -488,7 +740,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
                 nullptr, 1);
         }
         // the deformation launch (the longest) stays a pure GEMM: its last layer's slices ride with the two shorter launches
-        if (int e = launch_group(g, n, sm, 0, KID_WGRAD_D, M, det, st)) return e;
+        if (int e = launch_group(g, n, sm, 0, x3 ? KID_WGRAD_D_X3 : KID_WGRAD_D, M, det, x3, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
         // kernels (s, rho, tau, zbar) are fragment-ordered (their epilogues load AND store them: one dwordx4 per quad)
@@ -515,7 +767,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         }
         small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, 1);   // real rows only: d_sdf is [M]
         small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, 1);
-        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_S, M, det, st)) return e;
+        if (int e = launch_group(g, n, sm, ns, x3 ? KID_WGRAD_S_X3 : KID_WGRAD_S, M, det, x3, st)) return e;
     }
     if (flags & PF_COLOR) {
         n = 0;
@@ -532,7 +784,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         ns = 0;
         if (flags & PF_DEFORM) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
         small(B(WS_C_H) + (size_t)7 * t256, 256, B(WS_C_Y8), 4, Mc, 256, 3, dW(NET_C, 8), 256, dB(NET_C, 8), 1);
-        if (int e = launch_group(g, n, sm, ns, KID_WGRAD_C, Mc, det, st)) return e;
+        if (int e = launch_group(g, n, sm, ns, x3 ? KID_WGRAD_C_X3 : KID_WGRAD_C, Mc, det, x3, st)) return e;
     }
     return hip_last("point_wgrad");
 }

@@ -16,6 +16,7 @@ namespace es {
 constexpr int PF_DEFORM = 1;   // deformation network present (use_deform)
 constexpr int PF_COLOR = 2;    // evaluate the colour network (render_core) — off for errorondepth / surface_neighbour_error
 constexpr int PF_SAVE = 4;     // keep activations for the backward pass (training)
+constexpr int PF_X3 = 8;       // OPT-IN: weight-gradient GEMMs in split precision (3 x bf16 planes, wgrad.hip); no effect on layouts
 
 enum WsBuf : int {
     // forward outputs

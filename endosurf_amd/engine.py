@@ -40,10 +40,10 @@ class Engine:
         # (bit-identical results from run to run; a few % slower).  Also settable per renderer: ``renderer.engine.deterministic = True``
         self.deterministic = os.environ.get("ES_DETERMINISTIC", "0") not in ("0", "", "false", "False")
         self._wg_scratch = None
-        # opt-in split-precision mode (csrc/query_x3.hip): the large no-grad SDF queries (coarse samples, ray-marching proposals,
-        # field extraction) run on the bf16 matrix pipes with every fp32 operand split exactly into three bf16 planes (six partial
-        # products, fp32 accumulation): fp32-class accuracy at ~2.7x the fp32 MFMA rate.  NOT the default; also settable per
-        # renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
+        # opt-in split-precision mode (csrc/query_x3.hip, wgrad.hip): the large no-grad SDF queries (coarse samples, ray-marching
+        # proposals, field extraction) and the weight-gradient GEMMs run on the bf16 matrix pipes with every fp32 operand split
+        # exactly into three bf16 planes (six partial products, fp32 accumulation): fp32-class accuracy at ~2.7x the fp32 MFMA rate.
+        # NOT the default; also settable per renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
         self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
         self._x3 = None
 
@@ -334,7 +334,8 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, 
         assert d_rgb.shape[0] == mc
     if dweff is None:
         dweff = self.zeros(self.n_weff)
-    check(self.lib.es_point_backward_det(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
+    flags = ctx.flags | (_lib.PF_X3 if self.split_precision else 0)      # opt-in: weight-gradient GEMMs in split precision
+    check(self.lib.es_point_backward_det(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
                                          ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()), "es_point_backward")
     return dweff
 
