@@ -1,5 +1,14 @@
-"""PSNR parity (BASELINE.json): the HIP renderer trained on the build-owned synthetic scene follows the PSNR curve of the
-REFERENCE renderer trained (on CPU, tools/psnr_reference.py) with the same initial weights, batches and random draws."""
+"""PSNR parity (BASELINE.json "at matched PSNR"): the HIP renderer trained on the build-owned synthetic scene follows the PSNR curve
+of the REFERENCE renderer trained on CPU (tools/psnr_reference.py) with the same initial weights, batches and random draws, through
+the steep part and onto the PLATEAU of a complete schedule (1500 iterations, warm-up + cosine decay to 5 %).
+
+What "matched" can mean is bounded by the reference itself: training is chaotic, and two fp32 runs of the reference that differ only
+in the intra-op thread count (another GEMM summation order; tests/golden/psnr_reference_long.npz vs psnr_reference_t3.npz) drift
+apart by several dB at single evaluation points of the steep phase and re-converge on the plateau.  The test therefore asserts
+  (1) the same start and the same early trajectory (before rounding differences have been amplified);
+  (2) the plateau (mean of the last evaluations) within max(0.5 dB, 2x the reference's own run-to-run difference there);
+  (3) the same final loss level.
+The HIP run uses the deterministic reduction mode, so it is itself bit-reproducible (tests/test_gpu_determinism.py)."""
 import os
 
 import numpy as np
@@ -7,47 +16,76 @@ import pytest
 import torch
 
 import synth_scene
-import weightgen
 from gpu_util import renderer_for
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psnr_reference.npz")
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = os.path.join(GOLD_DIR, "psnr_reference_long.npz")
+GOLD_B = os.path.join(GOLD_DIR, "psnr_reference_t3.npz")
+N_TAIL = 4          # evaluations averaged on the plateau (iterations 1350..1500)
 
 
-@pytest.mark.skipif(not os.path.exists(GOLD), reason="reference PSNR curve not generated")
-def test_psnr_curve_matches_reference():
+def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True):
     from endosurf_amd.trainer import Trainer, cal_psnr
-    g = np.load(GOLD)
-    n_iter, n_rays = int(g["n_iter"]), int(g["n_rays"])
-    ref_curve, ref_loss = g["curve"], g["loss"]
-    r = renderer_for(int(g["weight_seed"]), "init", True)
+    r = renderer_for(weight_seed, "init", True)
+    r.engine.deterministic = deterministic
     tr = Trainer(r, lr=5e-4, n_iter=n_iter, warm_up_end=max(n_iter // 10, 1), lr_alpha=0.05, fused=True)
-    sched = synth_scene.schedule(int(g["sched_seed"]), n_iter, n_rays)
+    sched = synth_scene.schedule(sched_seed, n_iter, n_rays)
     ev = {k: torch.from_numpy(v).cuda() for k, v in synth_scene.eval_batch().items()}
+    eval_its = set(int(i) for i in eval_its)
     curve, losses = [], []
     for it in range(1, n_iter + 1):
         b = {k: torch.from_numpy(v).cuda() for k, v in sched[it - 1].items()}
         tr.update_learning_rate(it)
         loss, _, _ = tr.train_step(b, it, u_perturb=b["u_perturb"], u_neigh=b["u_neigh"])
         losses.append(loss)
-        if it % 10 == 0 or it == 1:
+        if it in eval_its:
             with torch.no_grad():
                 e = r(ev["rays"], iter_step=it, perturb_overwrite=False)
             curve.append((it, float(cal_psnr(e["color_map"], ev["color"], ev["mask"]))))
-    losses = torch.stack(losses).cpu().numpy()
-    curve = np.array(curve)
+    return np.array(curve), torch.stack(losses).cpu().numpy()
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="reference PSNR curve not generated (tools/psnr_reference.py)")
+def test_psnr_curve_matches_reference_to_the_plateau():
+    g = np.load(GOLD)
+    n_iter, n_rays = int(g["n_iter"]), int(g["n_rays"])
+    ref_curve, ref_loss = g["curve"], g["loss"]
+    curve, losses = _train(n_iter, n_rays, int(g["weight_seed"]), int(g["sched_seed"]), ref_curve[:, 0])
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    np.savez(os.path.join(out, "psnr_hip.npz"), curve=curve, loss=losses, ref_curve=ref_curve, ref_loss=ref_loss)
+    extra = {}
+    # the reference's own run-to-run difference (same code, same inputs, another thread count)
+    spread_tail, spread_max = 0.0, None
+    if os.path.exists(GOLD_B):
+        gb = np.load(GOLD_B)
+        n = min(len(gb["curve"]), len(ref_curve))
+        if n == len(ref_curve):
+            spread_tail = abs(float(np.mean(gb["curve"][-N_TAIL:, 1]) - np.mean(ref_curve[-N_TAIL:, 1])))
+        spread_max = float(np.max(np.abs(gb["curve"][:n, 1] - ref_curve[:n, 1])))
+        extra = dict(ref_b_curve=gb["curve"], ref_b_loss=gb["loss"])
+    np.savez(os.path.join(out, "psnr_hip.npz"), curve=curve, loss=losses, ref_curve=ref_curve, ref_loss=ref_loss, **extra)
     assert np.array_equal(curve[:, 0], ref_curve[:, 0])
     d = curve[:, 1] - ref_curve[:, 1]
-    # identical start (same weights), same trajectory early on, same quality at the end (training is chaotic in between)
+    # (1) identical start (same weights) and the same early trajectory (iterations 1..60)
     assert abs(d[0]) < 0.02, d[0]
-    assert np.max(np.abs(d[: min(4, len(d))])) < 0.3, d[:4]
-    # end quality: repeated runs of the SAME code end between ~27.9 and ~31.5 dB (fp32 atomics make the gradients
-    # non-deterministic and 300 Adam steps amplify that), the reference's single CPU run ends at 30.3 dB
-    end, ref_end = float(np.mean(curve[-3:, 1])), float(np.mean(ref_curve[-3:, 1]))
-    assert abs(end - ref_end) < 3.0, (end, ref_end)
-    assert curve[-1, 1] > curve[0, 1] + 3.0, "training must improve PSNR"
+    early = ref_curve[:, 0] <= 60
+    assert np.max(np.abs(d[early])) < 0.1, d[early]
+    # (2) the plateau: within max(0.5 dB, 2x the reference's own run-to-run difference)
+    end, ref_end = float(np.mean(curve[-N_TAIL:, 1])), float(np.mean(ref_curve[-N_TAIL:, 1]))
+    tol = max(0.5, 2.0 * spread_tail)
+    assert abs(end - ref_end) < tol, (end, ref_end, tol, spread_tail, spread_max)
+    assert end > curve[0, 1] + 15.0, "training must reach the reference's quality level"
+    # in between the curves may only differ as much as the reference differs from itself (+ margin)
+    if spread_max is not None:
+        assert np.max(np.abs(d)) < max(3.0, 1.5 * spread_max), (float(np.max(np.abs(d))), spread_max)
+    # (3) losses: identical first step, same level at the end
     assert abs(losses[0] - ref_loss[0]) < 2e-3 * max(1.0, abs(ref_loss[0]))
-    assert abs(np.mean(losses[-20:]) - np.mean(ref_loss[-20:])) < 0.15 * abs(np.mean(ref_loss[-20:])) + 0.02
+    assert abs(np.mean(losses[-100:]) - np.mean(ref_loss[-100:])) < 0.1 * abs(np.mean(ref_loss[-100:])) + 0.005
+
+
+def test_psnr_run_is_reproducible_in_deterministic_mode():
+    """Two deterministic runs of the first 60 iterations give the same losses and PSNR values bit for bit."""
+    a = _train(60, 256, 7, 11, [1, 30, 60])
+    b = _train(60, 256, 7, 11, [1, 30, 60])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
