@@ -157,14 +157,16 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2], const u32x4* __restric
         if (g + 1 < KG) load_b(b[(g + 1) & 1], g + 1);
         const u32x4(&aa)[3] = a[g % (PF + 1)];
         const u32x4(&bb)[2][3] = b[g & 1];
-        // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h); the two accumulators alternate
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int pb = 0; pb < 2; ++pb) {
+            // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h).  (Alternating the two accumulators per term instead was
+            // measured and is slower: 1.87 -> 2.11 ms for the 163 840 points of a training step.)
+            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int t = 0; t < 6; ++t)
                 acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa[TA[t]]), __builtin_bit_cast(bf16x8, bb[pb][TB[t]]),
                                                                   acc[pb], 0, 0, 0);
+        }
     }
 }
 

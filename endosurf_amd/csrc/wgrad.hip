@@ -353,7 +353,7 @@ constexpr int WX_R = 16;
 constexpr int WX_A_PLANE = 2 * 256 * 16;                     // 8 KiB
 constexpr int WX_B_PLANE = 2 * WG_KW * 16;                   // 4 KiB
 constexpr int WX_BUF = 3 * (WX_A_PLANE + WX_B_PLANE);        // 36 KiB per stage buffer
-constexpr int WX_LDS_BYTES = 2 * WX_BUF;                     // 72 KiB, one workgroup (8 waves, <= 256 registers) per CU
+constexpr int WX_LDS_BYTES = 4 * WX_BUF;                     // ring of four: 144 KiB, one workgroup (8 waves, <= 256 registers) per CU
 static_assert(WX_LDS_BYTES >= WG_LDS_FLOATS * 4, "the small-layer slices and the bias reduction reuse the buffer as float scratch");
 
 __device__ __forceinline__ unsigned wx_cvt_pk(float lo, float hi) {
@@ -469,7 +469,8 @@ __device__ __forceinline__ void wgrad_task_x3(const WgProb& P, int kb, int m0, i
                 b[t][p] = *reinterpret_cast<const wx_u32x4*>(Bb + p * WX_B_PLANE + t * 32 * 16);
             }
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};       // smallest partial products first
-        // partial product q of all four accumulators before q + 1: dependent MFMAs on one accumulator are 3 issues apart
+        // partial product q of all four accumulators before q + 1 (dependent MFMAs on one accumulator 3 issues apart): measured 5 %
+        // faster here than six dependent MFMAs per accumulator in a row (the opposite holds in query_x3.hip's loop)
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -480,21 +481,33 @@ __device__ __forceinline__ void wgrad_task_x3(const WgProb& P, int kb, int m0, i
                                                                         __builtin_bit_cast(wx_bf16x8, b[tp][TB[q]]), acc[t][tp], 0, 0, 0);
     };
 
-    const int nst = (m1 - m0) / WX_R;           // even (chunks are multiples of 64 rows)
-    WxRegs p0, p1;
+    // Software pipeline: the kernel is HBM-latency bound (one workgroup per CU), so the loads of stage st + 3 are issued at the
+    // start of stage st (four register sets, ~2.5 stages = 60 KB per CU in flight; with two sets the launch sustained 3.4 TB/s =
+    // 24 KB per stage time, Little's law) and the stages rotate through four LDS buffers with ONE barrier per stage.
+    const int nst = (m1 - m0) / WX_R;           // multiple of 4 (chunks are multiples of 64 rows): the body handles 4 stages
+    WxRegs p0, p1, p2, p3;
     gload(p0, m0);
     gload(p1, m0 + WX_R);
+    gload(p2, m0 + 2 * WX_R);
     sstore(p0, 0);
     __syncthreads();
 #pragma unroll 1
-    for (int st = 0; st < nst; st += 2) {
-        if (st + 2 < nst) gload(p0, m0 + WX_R * (st + 2));
+    for (int st = 0; st < nst; st += 4) {
+        gload(p3, m0 + WX_R * (st + 3));
         compute(0);
         sstore(p1, 1);
         __syncthreads();
-        if (st + 3 < nst) gload(p1, m0 + WX_R * (st + 3));
+        if (st + 4 < nst) gload(p0, m0 + WX_R * (st + 4));
         compute(1);
-        if (st + 2 < nst) sstore(p0, 0);
+        sstore(p2, 2);
+        __syncthreads();
+        if (st + 5 < nst) gload(p1, m0 + WX_R * (st + 5));
+        compute(2);
+        sstore(p3, 3);
+        __syncthreads();
+        if (st + 6 < nst) gload(p2, m0 + WX_R * (st + 6));
+        compute(3);
+        if (st + 4 < nst) sstore(p0, 0);
         __syncthreads();
     }
     // acc[t][tp][r]: n = nb*64 + 32 t + (r & 3) + 8 (r >> 2) + 4 hi ;  k = kb*128 + kh*64 + 32 tp + lo
