@@ -51,6 +51,7 @@ CONFIGS = {
 # per-point MACs of the three MLPs (SURVEY 8 / BASELINE.md 2)
 MAC_D, MAC_S, MAC_C = 459520, 544512, 638208
 PEAK_F32_MFMA = 157.3      # TFLOP/s, dense v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA = 2500.0    # TFLOP/s, dense v_mfma_f32_32x32x16_bf16 (same table); used for the opt-in split-precision kernels only
 
 
 def render_cfg(c):
@@ -320,15 +321,20 @@ def main():
             d = timing["dominant"]
             tr = pmc_traffic(d["kernel"])
             e2e = flops_per_step / (ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=d["tflops"], peak=PEAK_F32_MFMA, unit="TFLOP/s", frac=d["tflops"] / PEAK_F32_MFMA,
+            x3 = "_x3" in d["kernel"]
+            # a split-precision kernel issues SIX bf16 MACs per fp32-equivalent MAC: price it against the bf16 matrix peak
+            ach, peak = (d["tflops"] * 6.0, PEAK_BF16_MFMA) if x3 else (d["tflops"], PEAK_F32_MFMA)
+            roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
                         traffic=tr[0] if tr else None, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                         traffic_source=tr[1] if tr else None, kernel=d["kernel"],
                         kernel_choice="the kernel SYMBOL with the largest total time per step (all its launch sizes together)",
                         avg_launch_ms=d["avg_launch_ms"], launches=d["launches"], flops_per_launch=d["flops_per_launch"],
-                        share_of_timed_kernel_time=d["share_of_timed_kernel_time"],
+                        fp32_equivalent_tflops=d["tflops"], share_of_timed_kernel_time=d["share_of_timed_kernel_time"],
                         end_to_end=dict(achieved=e2e, frac=e2e / PEAK_F32_MFMA, unit="TFLOP/s", flops_per_step=flops_per_step,
-                                        note="executed GEMM FLOPs of one step (2 x MACs x points of every timed launch) / ms_per_step"),
-                        peak_note="fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)")
+                                        note="executed fp32-equivalent GEMM FLOPs of one step (2 x MACs x points of every timed launch) / "
+                                             "ms_per_step, against the fp32 MFMA peak"),
+                        peak_note=("bf16 MFMA dense peak (v_mfma_f32_32x32x16_bf16); achieved = 6 bf16 partial products per fp32-equivalent MAC"
+                                   if x3 else "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"))
         what = {"train": "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam",
                 "forward": "renderer forward only",
                 "frame": "one 640x512 frame per step, forward only, hipGraph-captured %d-ray chunks" % args.chunk + (" (eager)" if args.no_graph else "")}[mode]
