@@ -94,3 +94,126 @@ def test_synthetic_scene_rays_hit_the_unit_sphere():
     near, far = O.sphere_intersection(rays[:, :3], rays[:, 3:6])
     assert bool((far > near).all()) and bool((rays[:, 8] == rays[0, 8]).all())
     assert b["color"].shape == (256, 3) and float(b["depth"].min()) >= 1.2
+
+
+# ---- round 2 host logic -------------------------------------------------------------------------------------------------
+def _cpu_model(use_deform=True):
+    """The parameter container alone (flat buffer + reference-named views) lives happily on the CPU; only kernels need the GPU."""
+    from types import SimpleNamespace
+    from endosurf_amd.renderer import EndoSurfNet
+    torch.manual_seed(3)
+    m = EndoSurfNet(net_cfg(use_deform), "cpu")
+    m._pack_cache, m._flat_grad, m._epoch = None, None, 0
+    return m, SimpleNamespace(model=m, engine=None)
+
+
+@pytest.mark.parametrize("use_deform", [True, False])
+def test_flat_adam_state_dict_round_trips_through_torch_adam(use_deform):
+    """FlatAdam.state_dict() IS a torch.optim.Adam state_dict (the reference's ckpt["optimizer"], trainer_endosurf.py:76-92) and
+    FlatAdam.load_state_dict() accepts one: the flat moment buffers are scattered / gathered in get_train_params() order."""
+    from endosurf_amd.trainer import FlatAdam
+    m, r = _cpu_model(use_deform)
+    groups = m.get_train_params()
+    plist = [p for k in groups for p in groups[k]]
+    assert len(plist) == (82 if use_deform else 55)          # 27 tensors per network + the variance
+    opt = torch.optim.Adam(plist, lr=5e-4)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(2):
+        for p in plist:
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+    sd = opt.state_dict()
+    fa = FlatAdam(r)
+    fa.load_state_dict(sd)
+    assert fa.step_count == 2 and fa.param_groups[0]["lr"] == 5e-4
+    lay = m._layout
+    off, shape = lay["sdf_network.net.4.weight_v"]
+    idx = [i for i, p in enumerate(plist) if p is m.sdf_network.net[4].weight_v][0]
+    assert torch.equal(fa.exp_avg[off:off + 256 * 295].view(256, 295), sd["state"][idx]["exp_avg"])
+    voff = lay["deviation_network.variance"][0]
+    assert torch.equal(fa.exp_avg_sq[voff], sd["state"][len(plist) - 1]["exp_avg_sq"])
+    if not use_deform:                                       # the deformation slots of the flat buffer stay untouched
+        d0 = lay["deform_network.net.0.bias"][0]
+        assert float(fa.exp_avg[d0:lay["sdf_network.net.0.bias"][0]].abs().max()) == 0.0
+    # back: a fresh torch Adam accepts FlatAdam's state_dict and holds identical moments
+    sd2 = fa.state_dict()
+    assert set(sd2["param_groups"][0]) == set(sd["param_groups"][0])
+    opt2 = torch.optim.Adam(plist, lr=1.0)
+    opt2.load_state_dict(sd2)
+    for p in plist:
+        a, b = opt.state[p], opt2.state[p]
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"]) and float(a["step"]) == float(b["step"])
+    assert opt2.param_groups[0]["lr"] == 5e-4
+    # the flat round-1 format still loads
+    fa2 = FlatAdam(r)
+    fa2.load_state_dict(dict(step=2, exp_avg=fa.exp_avg.clone(), exp_avg_sq=fa.exp_avg_sq.clone(), param_groups=[dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)]))
+    assert fa2.step_count == 2 and torch.equal(fa2.exp_avg, fa.exp_avg)
+    with pytest.raises(ValueError):
+        bad = {"state": {}, "param_groups": [dict(sd["param_groups"][0], params=list(range(5)))]}
+        fa2.load_state_dict(bad)
+
+
+def test_rebound_parameters_are_folded_back_into_the_flat_buffer():
+    m, _ = _cpu_model(True)
+    p = m.color_network.net[2].bias
+    off = m._layout["color_network.net.2.bias"][0]
+    m._check_views()                                           # all views intact: nothing happens
+    e0 = m._epoch
+    p.data = torch.full_like(p.data, 0.5)                      # a loader re-binds the storage
+    assert p.data_ptr() != m._flat.data_ptr() + 4 * off
+    m._check_views()
+    assert p.data_ptr() == m._flat.data_ptr() + 4 * off and float(m._flat[off:off + 256].min()) == 0.5 and m._epoch > e0
+    with pytest.raises(TypeError):
+        m.double()                                             # fp32 on an AMD GPU only: never silently converted
+
+
+def test_bench_work_model_and_self_launch(monkeypatch):
+    import importlib
+    import bench
+    importlib.reload(bench)
+    c2, c4 = bench.CONFIGS[2], bench.CONFIGS[4]
+    a2, a4 = bench.algorithmic_gflop_per_ray(c2), bench.algorithmic_gflop_per_ray(c4)
+    D, S, C = bench.MAC_D, bench.MAC_S, bench.MAC_C
+    assert a2["upsample"] * 1e9 == pytest.approx(2 * 56 * (D + S)) and a2["render_core_forward"] * 1e9 == pytest.approx(2 * 64 * (3 * D + 2 * S + C))
+    assert a4["render_core_forward"] * 1e9 == pytest.approx(2 * 64 * (2 * S + C))          # no deformation network
+    assert bench.kernel_macs("k_query_sdf", False) == S and bench.kernel_macs("k_wgrad[deform]", True) == 3 * D
+    assert bench.kernel_macs("k_query_sdf[later marching blocks: tiles of finished rays exit]", True) is None      # never counted as work
+    assert bench.render_cfg(bench.CONFIGS[3])["n_samples"] == 64 and bench.CONFIGS[3]["rays"] == 2048
+    # `python bench.py --gpus 4` without a launcher in the environment re-executes itself under torch.distributed.run
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_workspace_budget_chunking_arithmetic():
+    """_chunk_rays: rays per chunk of a grad-enabled render under render_cfg["workspace_gb"] (host arithmetic over the C layout query)."""
+    from types import SimpleNamespace
+    from endosurf_amd import _lib
+    from endosurf_amd.renderer import EndoSurfRenderer
+    lib = _lib.load()
+    flags = _lib.PF_DEFORM | _lib.PF_SAVE
+    per_point = 4.0 * lib.es_point_workspace_floats(65536, flags | _lib.PF_COLOR) / 65536
+    assert 90e3 < per_point < 120e3                                  # ~103 KB of saved activations per point
+    fake = SimpleNamespace(workspace_gb=64.0, engine=SimpleNamespace(lib=lib), __dict__={})
+    f = lambda N, S, fl=flags: EndoSurfRenderer._chunk_rays(fake, N, S, fl)
+    assert f(1024, 64) == 0 and f(2048, 128) == 0                     # configs 2 and 3 fit
+    c = f(327680, 64)                                                 # a full frame under grad: chunked
+    assert c > 0 and c % 64 == 0 and c * 64 * per_point <= 64e9 < (c + 64) * 64 * per_point
+    assert f(327680, 64, _lib.PF_DEFORM) == 0                         # no saved activations: no budget applies
+    fake.workspace_gb = 1e-3
+    fake.__dict__.pop("_budget_points", None)
+    with pytest.raises(_lib.EndoSurfHipError, match="workspace_gb"):
+        f(1024, 64)
