@@ -30,7 +30,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int X3_THREADS = 512;
 constexpr int X3_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7};
 constexpr int X3_COUNT = sizeof(X3_SEGS) / sizeof(int);
 constexpr int x3_kg(int i) { return cdiv(SEGS[X3_SEGS[i]].kreal, 16); }
@@ -107,46 +106,66 @@ __global__ __launch_bounds__(256) void k_pack_x3(const float* __restrict__ weff,
 }
 
 // ---- LDS operand planes -------------------------------------------------------------------------------------------------
-// plane p of a K-wide operand: [K/8][64 points] units of 16 B (8 consecutive k of one point)
-constexpr int X3_MAIN_K8 = 32, X3_ENC_K8 = 8;
-constexpr int X3_MAIN_PLANE = X3_MAIN_K8 * 64 * 16;          // 32 KiB
-constexpr int X3_ENC_PLANE = X3_ENC_K8 * 64 * 16;            //  8 KiB
-constexpr int X3_LDS_BYTES = 3 * X3_MAIN_PLANE + 3 * X3_ENC_PLANE + (256 + 8 * 3 * 64) * 4;     // 130 048 B: one workgroup per CU
+// plane p of a K-wide operand: [K/8][PTS points] units of 16 B (8 consecutive k of one point).
+// Two tile shapes: PTS = 64 (8 waves, wave = 32 features x 64 points, 127 KB of LDS: one workgroup per CU) and PTS = 32 (4 waves,
+// wave = 64 features x 32 points, 64 KB: TWO workgroups per CU whose GEMM and epilogue phases interleave on the SIMDs, at twice the
+// weight traffic from L2).  Measured (163 840 points of a training step): 1.90 ms vs 2.70 ms -- the 384 KB of split weights per layer
+// and tile make the short tile L2-bound (62 B/clk/CU at full MFMA rate), so the host launches PTS = 64 (-DX3_PTS=32 builds the other).
+#ifndef X3_PTS
+#define X3_PTS 64
+#endif
+template <int PTS>
+struct X3Cfg {
+    static constexpr int PB = PTS / 32;                 // point blocks of a wave tile
+    static constexpr int FB = 2 / PB;                   // feature blocks of a wave tile
+    static constexpr int WAVES = 8 / FB;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int MAIN_PLANE = 32 * PTS * 16;
+    static constexpr int ENC_PLANE = 8 * PTS * 16;
+    static constexpr int PARTS = THREADS / PTS;          // 8 thread groups for the per-point VALU stages
+    static constexpr int LDS_BYTES = 3 * MAIN_PLANE + 3 * ENC_PLANE + (4 * PTS + PARTS * 3 * PTS) * 4;
+    static_assert(PARTS == 8, "the per-point stages split k / the encoding items over 8 thread groups");
+};
 
+template <int PTS>
 __device__ __forceinline__ void put_x3(unsigned char* planes, int plane_bytes, int k, int p, float v) {      // one element
     const unsigned h = cvt_pk_bf16(v, 0.f);
     const float r1 = v - __uint_as_float(h << 16);
     const unsigned m = cvt_pk_bf16(r1, 0.f);
     const unsigned l = cvt_pk_bf16(r1 - __uint_as_float(m << 16), 0.f);
-    const int o = ((k >> 3) * 64 + p) * 16 + (k & 7) * 2;
+    const int o = ((k >> 3) * PTS + p) * 16 + (k & 7) * 2;
     *reinterpret_cast<unsigned short*>(planes + o) = (unsigned short)h;
     *reinterpret_cast<unsigned short*>(planes + plane_bytes + o) = (unsigned short)m;
     *reinterpret_cast<unsigned short*>(planes + 2 * plane_bytes + o) = (unsigned short)l;
 }
+template <int PTS>
 __device__ __forceinline__ float get_x3(const unsigned char* planes, int plane_bytes, int k, int p) {
-    const int o = ((k >> 3) * 64 + p) * 16 + (k & 7) * 2;
+    const int o = ((k >> 3) * PTS + p) * 16 + (k & 7) * 2;
     const unsigned h = *reinterpret_cast<const unsigned short*>(planes + o), m = *reinterpret_cast<const unsigned short*>(planes + plane_bytes + o),
                    l = *reinterpret_cast<const unsigned short*>(planes + 2 * plane_bytes + o);
     return __uint_as_float(h << 16) + (__uint_as_float(m << 16) + __uint_as_float(l << 16));
 }
 
-// acc[pb] += W[features 32 wave ..][0 .. 16 KG) . X^T[0 .. 16 KG)[points 32 pb ..]     (six partial products per tile)
-template <int KG>
-__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2], const u32x4* __restrict__ W, const unsigned char* X, int plane_bytes, int wave,
-                                        int lane) {
-    const u32x4* wl = W + (size_t)wave * KG * 3 * 64 + lane;
-    const unsigned char* xb = X + ((lane >> 5) * 64 + (lane & 31)) * 16;
+// acc[fi][pb] += W[features 32 (FB wave + fi) ..][0 .. 16 KG) . X^T[0 .. 16 KG)[points 32 pb ..]     (six partial products per tile)
+template <int KG, int PTS>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[X3Cfg<PTS>::FB][X3Cfg<PTS>::PB], const u32x4* __restrict__ W, const unsigned char* X,
+                                        int plane_bytes, int wave, int lane) {
+    constexpr int FB = X3Cfg<PTS>::FB, PB = X3Cfg<PTS>::PB;
+    const u32x4* wl = W + (size_t)(wave * FB) * KG * 3 * 64 + lane;
+    const unsigned char* xb = X + ((lane >> 5) * PTS + (lane & 31)) * 16;
     constexpr int PF = 3;                       // weight fragments in flight: three k-steps ahead (L2 latency)
-    u32x4 a[PF + 1][3], b[2][2][3];
-    auto load_a = [&](u32x4(&d)[3], int g) {
+    u32x4 a[PF + 1][FB][3], b[2][PB][3];
+    auto load_a = [&](u32x4(&d)[FB][3], int g) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) d[p] = wl[(size_t)(g * 3 + p) * 64];
+        for (int fi = 0; fi < FB; ++fi)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[fi][p] = wl[(size_t)((fi * KG + g) * 3 + p) * 64];
     };
-    auto load_b = [&](u32x4(&d)[2][3], int g) {
+    auto load_b = [&](u32x4(&d)[PB][3], int g) {
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) d[pb][p] = *reinterpret_cast<const u32x4*>(xb + p * plane_bytes + (2 * g) * 64 * 16 + pb * 32 * 16);
+            for (int p = 0; p < 3; ++p) d[pb][p] = *reinterpret_cast<const u32x4*>(xb + p * plane_bytes + (2 * g) * PTS * 16 + pb * 32 * 16);
     };
 #pragma unroll
     for (int s = 0; s < PF && s < KG; ++s) load_a(a[s], s);
@@ -155,220 +174,232 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2], const u32x4* __restric
     for (int g = 0; g < KG; ++g) {
         if (g + PF < KG) load_a(a[(g + PF) % (PF + 1)], g + PF);
         if (g + 1 < KG) load_b(b[(g + 1) & 1], g + 1);
-        const u32x4(&aa)[3] = a[g % (PF + 1)];
-        const u32x4(&bb)[2][3] = b[g & 1];
+        const u32x4(&aa)[FB][3] = a[g % (PF + 1)];
+        const u32x4(&bb)[PB][3] = b[g & 1];
+        // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h); six dependent MFMAs per accumulator in a row (alternating the
+        // accumulators per term was measured and is slower in this loop: 1.87 -> 2.11 ms per training step)
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h).  (Alternating the two accumulators per term instead was
-            // measured and is slower: 1.87 -> 2.11 ms for the 163 840 points of a training step.)
-            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+        for (int fi = 0; fi < FB; ++fi)
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa[TA[t]]), __builtin_bit_cast(bf16x8, bb[pb][TB[t]]),
-                                                                  acc[pb], 0, 0, 0);
-        }
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    acc[fi][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa[fi][TA[t]]),
+                                                                         __builtin_bit_cast(bf16x8, bb[pb][TB[t]]), acc[fi][pb], 0, 0, 0);
     }
 }
 
-// epilogue visitor: f(f0, p, v[4]) with v = features f0 .. f0+3 (f0 = 32 wave + 8 q + 4 hi) of point p = 32 pb + lo
-template <class F>
-__device__ __forceinline__ void for_quads_x3(f32x16 (&acc)[2], int wave, int lane, F&& f) {
+// epilogue visitor: f(f0, p, v[4]) with v = features f0 .. f0+3 (f0 = 32 (FB wave + fi) + 8 q + 4 hi) of point p = 32 pb + lo
+template <int PTS, class F>
+__device__ __forceinline__ void for_quads_x3(f32x16 (&acc)[X3Cfg<PTS>::FB][X3Cfg<PTS>::PB], int wave, int lane, F&& f) {
+    constexpr int FB = X3Cfg<PTS>::FB, PB = X3Cfg<PTS>::PB;
     const int lo = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int fi = 0; fi < FB; ++fi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[4] = {acc[pb][4 * q + 0], acc[pb][4 * q + 1], acc[pb][4 * q + 2], acc[pb][4 * q + 3]};
-            f(32 * wave + 8 * q + 4 * hi, 32 * pb + lo, v);
-        }
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[fi][pb][4 * q + 0], acc[fi][pb][4 * q + 1], acc[fi][pb][4 * q + 2], acc[fi][pb][4 * q + 3]};
+                f(32 * (wave * FB + fi) + 8 * q + 4 * hi, 32 * pb + lo, v);
+            }
 }
 // store features f0..f0+3 of point p into the three main planes (half of one [k/8][point] unit: ds_write_b64)
+template <int PTS>
 __device__ __forceinline__ void store_quad_x3(unsigned char* X, int f0, int p, const float (&v)[4]) {
     unsigned h0, m0, l0, h1, m1, l1;
     split_pair(v[0], v[1], h0, m0, l0);
     split_pair(v[2], v[3], h1, m1, l1);
-    const int o = ((f0 >> 3) * 64 + p) * 16 + (f0 & 7) * 2;
+    const int o = ((f0 >> 3) * PTS + p) * 16 + (f0 & 7) * 2;
     *reinterpret_cast<u32x2*>(X + o) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(X + X3_MAIN_PLANE + o) = u32x2{m0, m1};
-    *reinterpret_cast<u32x2*>(X + 2 * X3_MAIN_PLANE + o) = u32x2{l0, l1};
+    *reinterpret_cast<u32x2*>(X + X3Cfg<PTS>::MAIN_PLANE + o) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(X + 2 * X3Cfg<PTS>::MAIN_PLANE + o) = u32x2{l0, l1};
 }
-__device__ __forceinline__ void acc2_zero(f32x16 (&acc)[2]) {
+template <int FB, int PB>
+__device__ __forceinline__ void accx_zero(f32x16 (&acc)[FB][PB]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
 // out[i][p] = sum_k Wrows[i][k] x[p][k] over the 256-wide main planes: 8 thread groups x 32 k each
-template <int NOUT>
+template <int NOUT, int PTS>
 __device__ __forceinline__ void smalln_x3(const unsigned char* X, const float* __restrict__ Wrows, float* red, int tid) {
-    const int p = tid & 63, part = tid >> 6;
+    const int p = tid % PTS, part = tid / PTS;
     float s[NOUT];
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) s[i] = 0.f;
 #pragma unroll 4
     for (int kk = 0; kk < 32; ++kk) {
         const int k = 32 * part + kk;
-        const float x = get_x3(X, X3_MAIN_PLANE, k, p);
+        const float x = get_x3<PTS>(X, X3Cfg<PTS>::MAIN_PLANE, k, p);
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) s[i] = fmaf(Wrows[i * 256 + k], x, s[i]);
     }
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) red[(part * NOUT + i) * 64 + p] = s[i];
+    for (int i = 0; i < NOUT; ++i) red[(part * NOUT + i) * PTS + p] = s[i];
 }
-template <int NOUT>
+template <int NOUT, int PTS>
 __device__ __forceinline__ float smalln_x3_reduce(const float* red, int i, int p) {
     float s = 0.f;
 #pragma unroll
-    for (int part = 0; part < 8; ++part) s += red[(part * NOUT + i) * 64 + p];
+    for (int part = 0; part < 8; ++part) s += red[(part * NOUT + i) * PTS + p];
     return s;
 }
 
-template <int L>
+template <int L, int PTS>
 __device__ __forceinline__ void encode3_x3(unsigned char* E, int kbase, const float* px, int tid) {
-    const int p = tid & 63, part = tid >> 6;
+    const int p = tid % PTS, part = tid / PTS;
     for (int item = part; item < 3 * L; item += 8) {
         const int c = item % 3, i = item / 3;
         float s, co;
-        sincosf(px[c * 64 + p] * (float)(1 << i), &s, &co);
-        put_x3(E, X3_ENC_PLANE, kbase + enc_index(3, i, 0, c), p, s);
-        put_x3(E, X3_ENC_PLANE, kbase + enc_index(3, i, 1, c), p, co);
+        sincosf(px[c * PTS + p] * (float)(1 << i), &s, &co);
+        put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(3, i, 0, c), p, s);
+        put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(3, i, 1, c), p, co);
     }
     if (part == 7) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put_x3(E, X3_ENC_PLANE, kbase + c, p, px[c * 64 + p]);
+        for (int c = 0; c < 3; ++c) put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + c, p, px[c * PTS + p]);
     }
 }
-template <int L>
+template <int L, int PTS>
 __device__ __forceinline__ void encode1_x3(unsigned char* E, int kbase, const float* pt, int tid) {
-    const int p = tid & 63, part = tid >> 6;
+    const int p = tid % PTS, part = tid / PTS;
     for (int i = part; i < L; i += 8) {
         float s, co;
         sincosf(pt[p] * (float)(1 << i), &s, &co);
-        put_x3(E, X3_ENC_PLANE, kbase + enc_index(1, i, 0, 0), p, s);
-        put_x3(E, X3_ENC_PLANE, kbase + enc_index(1, i, 1, 0), p, co);
+        put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(1, i, 0, 0), p, s);
+        put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(1, i, 1, 0), p, co);
     }
-    if (part == 6) put_x3(E, X3_ENC_PLANE, kbase, p, pt[p]);
+    if (part == 6) put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase, p, pt[p]);
 }
+template <int PTS>
 __device__ __forceinline__ void zero_enc_x3(unsigned char* E, int tid) {       // all three encoding planes (padding k must read as 0)
-    for (int i = tid; i < 3 * X3_ENC_PLANE / 16; i += X3_THREADS) reinterpret_cast<u32x4*>(E)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 3 * X3Cfg<PTS>::ENC_PLANE / 16; i += X3Cfg<PTS>::THREADS) reinterpret_cast<u32x4*>(E)[i] = u32x4{0u, 0u, 0u, 0u};
 }
 
-template <bool DEFORM>
-__global__ __launch_bounds__(X3_THREADS, 1) void k_query_sdf_x3(PointSrc src, Tabs tb, X3Tabs xt, const u32x4* __restrict__ packed,
-                                                               const float* __restrict__ weff, float* __restrict__ sdf_out, int ld_out,
-                                                               const int* __restrict__ ray_done) {
+template <bool DEFORM, int PTS>
+__global__ __launch_bounds__(X3Cfg<PTS>::THREADS, 1) void k_query_sdf_x3(PointSrc src, Tabs tb, X3Tabs xt, const u32x4* __restrict__ packed,
+                                                                       const float* __restrict__ weff, float* __restrict__ sdf_out, int ld_out,
+                                                                       const int* __restrict__ ray_done) {
+    using Cfg = X3Cfg<PTS>;
+    constexpr int FB = Cfg::FB, PB = Cfg::PB, MAIN_PLANE = Cfg::MAIN_PLANE, ENC_PLANE = Cfg::ENC_PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     unsigned char* X = lds3;                                  // main activation planes
-    unsigned char* E = lds3 + 3 * X3_MAIN_PLANE;              // encoding planes
-    float* scr = reinterpret_cast<float*>(E + 3 * X3_ENC_PLANE);
-    float* px = scr;           // [3][64]
-    float* pt = scr + 192;     // [64]
-    float* red = scr + 256;    // [8][<=3][64]
+    unsigned char* E = lds3 + 3 * MAIN_PLANE;                 // encoding planes
+    float* scr = reinterpret_cast<float*>(E + 3 * ENC_PLANE);
+    float* px = scr;               // [3][PTS]
+    float* pt = scr + 3 * PTS;     // [PTS]
+    float* red = scr + 4 * PTS;    // [8][<=3][PTS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * 64;
+    const int row0 = blockIdx.x * PTS;
     if (ray_done != nullptr) {      // block-wise ray marching: a tile whose rays already have their first sign change is skipped
-        const int r_first = row0 / src.n_per_ray, r_last = min(row0 + 63, src.M - 1) / src.n_per_ray;
+        const int r_first = row0 / src.n_per_ray, r_last = min(row0 + PTS - 1, src.M - 1) / src.n_per_ray;
         bool all_done = true;
         for (int r = r_first; r <= r_last; ++r) all_done = all_done && ray_done[r] != 0;
         if (all_done) return;       // workgroup-uniform
     }
-    if (tid < 64) {
+    if (tid < PTS) {
         float x[3], t, d[3];
         load_point(src, row0 + tid, x, t, d);
-        px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2]; pt[tid] = t;
+        px[tid] = x[0]; px[PTS + tid] = x[1]; px[2 * PTS + tid] = x[2]; pt[tid] = t;
     }
-    zero_enc_x3(E, tid);
+    zero_enc_x3<PTS>(E, tid);
     __syncthreads();
 
     auto W = [&](int seg) { return packed + xt.off[seg]; };
+    auto bias4 = [&](const float* bias, int f0) { return make_float4(bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]); };   // dword aligned only
     if (DEFORM) {
         // ---- deformation MLP, value only: x_c = x + MLP([enc6(x), enc6(t)]) ----
-        encode3_x3<6>(E, 0, px, tid);
-        encode1_x3<6>(E, 39, pt, tid);
+        encode3_x3<6, PTS>(E, 0, px, tid);
+        encode1_x3<6, PTS>(E, 39, pt, tid);
         __syncthreads();
         {
-            f32x16 acc[2];
-            acc2_zero(acc);
-            gemm_x3<4>(acc, W(X3_DF0), E, X3_ENC_PLANE, wave, lane);
+            f32x16 acc[FB][PB];
+            accx_zero(acc);
+            gemm_x3<4, PTS>(acc, W(X3_DF0), E, ENC_PLANE, wave, lane);
             const float* bias = weff + tb.boff[NET_D * LAYERS + 0];
-            for_quads_x3(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
-                const float4 b = make_float4(bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]);   // weff offsets are only dword aligned
+            for_quads_x3<PTS>(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
+                const float4 b = bias4(bias, f0);
                 v[0] = fmaxf(v[0] + b.x, 0.f); v[1] = fmaxf(v[1] + b.y, 0.f); v[2] = fmaxf(v[2] + b.z, 0.f); v[3] = fmaxf(v[3] + b.w, 0.f);
-                store_quad_x3(X, f0, p, v);
+                store_quad_x3<PTS>(X, f0, p, v);
             });
         }
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
-            f32x16 acc[2];
-            acc2_zero(acc);
-            gemm_x3<16>(acc, W(X3_DF0 + l), X, X3_MAIN_PLANE, wave, lane);
+            f32x16 acc[FB][PB];
+            accx_zero(acc);
+            gemm_x3<16, PTS>(acc, W(X3_DF0 + l), X, MAIN_PLANE, wave, lane);
             __syncthreads();
             const float* bias = weff + tb.boff[NET_D * LAYERS + l];
-            for_quads_x3(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
+            for_quads_x3<PTS>(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
                 if (l == 3 && f0 >= 204) {       // IDR skip: next input = [h(204) | enc(52)] (1/sqrt2 folded into W4); 204 % 4 == 0
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = get_x3(E, X3_ENC_PLANE, f0 - 204 + i, p);
+                    for (int i = 0; i < 4; ++i) v[i] = get_x3<PTS>(E, ENC_PLANE, f0 - 204 + i, p);
                 } else {
                     // layer 3 has 204 outputs: its bias vector is 204 long and a quad never straddles the boundary
-                    const float4 b = make_float4(bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]);   // weff offsets are only dword aligned
+                    const float4 b = bias4(bias, f0);
                     v[0] = fmaxf(v[0] + b.x, 0.f); v[1] = fmaxf(v[1] + b.y, 0.f); v[2] = fmaxf(v[2] + b.z, 0.f); v[3] = fmaxf(v[3] + b.w, 0.f);
                 }
-                store_quad_x3(X, f0, p, v);
+                store_quad_x3<PTS>(X, f0, p, v);
             });
             __syncthreads();
         }
-        smalln_x3<3>(X, weff + tb.woff[NET_D * LAYERS + 8], red, tid);
+        smalln_x3<3, PTS>(X, weff + tb.woff[NET_D * LAYERS + 8], red, tid);
         __syncthreads();
-        if (tid < 192) {
-            const int i = tid >> 6, p = tid & 63;
-            px[i * 64 + p] += smalln_x3_reduce<3>(red, i, p) + weff[tb.boff[NET_D * LAYERS + 8] + i];
+        if (tid < 3 * PTS) {
+            const int i = tid / PTS, p = tid % PTS;
+            px[i * PTS + p] += smalln_x3_reduce<3, PTS>(red, i, p) + weff[tb.boff[NET_D * LAYERS + 8] + i];
         }
         __syncthreads();
-        zero_enc_x3(E, tid);
+        zero_enc_x3<PTS>(E, tid);
         __syncthreads();
     }
 
     // ---- SDF MLP on x_c, output column 0 only ----
-    encode3_x3<6>(E, 0, px, tid);
+    encode3_x3<6, PTS>(E, 0, px, tid);
     __syncthreads();
     {
-        f32x16 acc[2];
-        acc2_zero(acc);
-        gemm_x3<3>(acc, W(X3_SF0), E, X3_ENC_PLANE, wave, lane);
+        f32x16 acc[FB][PB];
+        accx_zero(acc);
+        gemm_x3<3, PTS>(acc, W(X3_SF0), E, ENC_PLANE, wave, lane);
         const float* bias = weff + tb.boff[NET_S * LAYERS + 0];
-        for_quads_x3(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
-            const float4 b = make_float4(bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]);   // weff offsets are only dword aligned
+        for_quads_x3<PTS>(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
+            const float4 b = bias4(bias, f0);
             v[0] = softplus100(v[0] + b.x); v[1] = softplus100(v[1] + b.y); v[2] = softplus100(v[2] + b.z); v[3] = softplus100(v[3] + b.w);
-            store_quad_x3(X, f0, p, v);
+            store_quad_x3<PTS>(X, f0, p, v);
         });
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2];
-        acc2_zero(acc);
+        f32x16 acc[FB][PB];
+        accx_zero(acc);
         // X3_SEGS order: ..., SF3, SF4M, SF4A, SF5, ...
         const int si = X3_SF0 + (l <= 4 ? l : l + 1);
-        gemm_x3<16>(acc, W(si), X, X3_MAIN_PLANE, wave, lane);
-        if (l == 4) gemm_x3<3>(acc, W(X3_SF4A), E, X3_ENC_PLANE, wave, lane);   // NeRF skip: + encoding part
+        gemm_x3<16, PTS>(acc, W(si), X, MAIN_PLANE, wave, lane);
+        if (l == 4) gemm_x3<3, PTS>(acc, W(X3_SF4A), E, ENC_PLANE, wave, lane);   // NeRF skip: + encoding part
         __syncthreads();
         const float* bias = weff + tb.boff[NET_S * LAYERS + l];
-        for_quads_x3(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
-            const float4 b = make_float4(bias[f0], bias[f0 + 1], bias[f0 + 2], bias[f0 + 3]);   // weff offsets are only dword aligned
+        for_quads_x3<PTS>(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
+            const float4 b = bias4(bias, f0);
             v[0] = softplus100(v[0] + b.x); v[1] = softplus100(v[1] + b.y); v[2] = softplus100(v[2] + b.z); v[3] = softplus100(v[3] + b.w);
-            store_quad_x3(X, f0, p, v);
+            store_quad_x3<PTS>(X, f0, p, v);
         });
         __syncthreads();
     }
-    smalln_x3<1>(X, weff + tb.woff[NET_S * LAYERS + 8], red, tid);
+    smalln_x3<1, PTS>(X, weff + tb.woff[NET_S * LAYERS + 8], red, tid);
     __syncthreads();
-    if (tid < 64 && row0 + tid < src.M) {
+    if (tid < PTS && row0 + tid < src.M) {
         const int i = row0 + tid;
         const size_t o = ld_out > 0 ? (size_t)(i / src.n_per_ray) * ld_out + (i % src.n_per_ray) : (size_t)i;   // [ray][ld_out] or flat
-        sdf_out[o] = smalln_x3_reduce<1>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
+        sdf_out[o] = smalln_x3_reduce<1, PTS>(red, 0, tid) + weff[tb.boff[NET_S * LAYERS + 8]];
     }
 }
 
@@ -392,20 +423,22 @@ int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st) 
 
 int query_sdf_x3(const PointSrc& src, const void* packed_x3, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
                  const int* ray_done) {
+    constexpr int PTS = X3_PTS;
+    using Cfg = X3Cfg<PTS>;
     static DeviceOnce attr_done;
     if (attr_done.first()) {
-        if (int e = allow_big_lds(k_query_sdf_x3<true>, X3_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf_x3<false>, X3_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<true, PTS>, Cfg::LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<false, PTS>, Cfg::LDS_BYTES)) return e;
         attr_done.done();
     }
     if (src.M <= 0) return ST_OK;
     const Tabs tb = make_tabs();
     const X3Tabs xt = make_x3_tabs();
-    const dim3 grid((src.M + 63) / 64), block(X3_THREADS);
+    const dim3 grid((src.M + PTS - 1) / PTS), block(Cfg::THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_x3);
     ScopedTimer tm(ray_done ? KID_QUERY_EXIT : KID_QUERY_X3, src.M, st);
-    if (use_deform) hipLaunchKernelGGL(k_query_sdf_x3<true>, grid, block, X3_LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
-    else hipLaunchKernelGGL(k_query_sdf_x3<false>, grid, block, X3_LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
+    if (use_deform) hipLaunchKernelGGL((k_query_sdf_x3<true, PTS>), grid, block, Cfg::LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
+    else hipLaunchKernelGGL((k_query_sdf_x3<false, PTS>), grid, block, Cfg::LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
     return hip_last("query_sdf_x3");
 }
 
