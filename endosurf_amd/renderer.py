@@ -82,18 +82,49 @@ class _MLP(nn.Module):
     def __init__(self, flat, lay, net_name):
         super().__init__()
         self.net = nn.ModuleList([WNLinear(flat, lay, f"{net_name}.net.{l}") for l in range(9)])
+        self._model = None          # weakref to the owning EndoSurfNet (set there): the forwards below run the fused kernels
+
+    def _ctx(self):
+        m = self._model() if self._model is not None else None
+        if m is None:
+            raise RuntimeError("this network is not attached to an EndoSurfNet / EndoSurfRenderer")
+        return m, m._r()
 
 
 class DeformNetwork(_MLP):
-    pass
+    def forward(self, x, t):
+        """Displacement field delta x(x, t) [M,3] (reference DeformNetwork.forward, endosurf.py:724-738), no grad: x_c of the fused
+        point evaluation minus x."""
+        m, r = self._ctx()
+        with torch.cuda.device(r.device), torch.no_grad():
+            x, t = m._xt(x, t)
+            weff, packed = r._weights()
+            pctx = r.engine.point_forward(r.engine.points(x=x, t=t), weff.detach(), packed, _lib.PF_DEFORM)
+            return pctx.view("xc") - x
 
 
 class SDFNetwork(_MLP):
-    pass
+    def forward(self, x):
+        """[sdf | 256 geometry features] [M,257] at CANONICAL points (reference SDFNetwork.forward, endosurf.py:773-786), no grad."""
+        m, r = self._ctx()
+        with torch.cuda.device(r.device), torch.no_grad():
+            x, t = m._xt(x, torch.zeros(1, device=x.device))
+            weff, packed = r._weights()
+            d = torch.zeros_like(x)
+            d[:, 2] = 1.0
+            pctx = r.engine.point_forward(r.engine.points(x=x, t=t, dirs=d), weff.detach(), packed, _lib.PF_COLOR)   # features need the colour path's buffers
+            return torch.cat([pctx.view("sdf"), pctx.view("feat")], -1)
+
+    def sdf(self, x):
+        """sdf [M,1] at canonical points (endosurf.py:788-791)."""
+        return self.forward(x)[..., :1]
 
 
 class ColorNetwork(_MLP):
-    pass
+    def forward(self, x, n, d, geo_feat):
+        raise NotImplementedError(
+            "the colour MLP is evaluated only inside the fused chain (x_c, g_c, d_c and the features never leave the chip); use "
+            "EndoSurfNet.forward / EndoSurfRenderer.renderonpts for colours at given points")
 
 
 class SingleVarianceNetwork(nn.Module):
@@ -101,6 +132,10 @@ class SingleVarianceNetwork(nn.Module):
         super().__init__()
         off, _ = lay["deviation_network.variance"]
         self.register_parameter("variance", nn.Parameter(flat[off:off + 1].view(())))
+
+    def forward(self, x):
+        """inv_s broadcast to [len(x), 1] (endosurf.py:850-852); plain torch, differentiable w.r.t. the variance."""
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
 
 
 def _reference_style_init(flat: torch.Tensor, lay: dict, net_cfg: dict):
@@ -158,6 +193,8 @@ class EndoSurfNet(nn.Module):
         self.color_network = ColorNetwork(self._flat, lay, "color_network")
         self.deviation_network = SingleVarianceNetwork(self._flat, lay)
         self._layout = lay
+        for net in ((self.deform_network,) if self.use_deform else ()) + (self.sdf_network, self.color_network):
+            net._model = weakref.ref(self)
 
     def get_train_params(self):
         out = {}

@@ -158,3 +158,28 @@ def test_surface_neighbour_error_documented_divergences():
     valid = (torch.isfinite(d_i) & (d_i != 0) & (mask == 1))[:, 0]
     un2 = torch.where(valid[:, None], un, torch.rand_like(un))
     assert float(r.surface_neighbour_error(rays, mask, neighbour_rad=0.1, u_neigh=un2)) == float(sn)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sub_network_forwards(name):
+    """renderer.model.{deform_network(x, t), sdf_network(x_c), sdf_network.sdf(x_c), deviation_network(x)} (endosurf.py:724-852)
+    against the reference's pt64/* vectors; the colour network alone is refused with an explanation."""
+    c = load_case(name)
+    r = renderer_for_case(c)
+    m = r.model
+    x, t = torch.from_numpy(c["pt/x"]).cuda(), torch.from_numpy(c["pt/t"]).cuda()
+    if r.use_deform:
+        dx = m.deform_network(x, t)
+        assert np.max(np.abs(dx.cpu().numpy() - c["pt64/deform"])) < 1e-5
+        x_c = x + torch.from_numpy(c["pt64/deform"]).cuda()
+    else:
+        x_c = x
+    h = m.sdf_network(x_c).cpu().numpy()
+    assert h.shape == (x.shape[0], 257)
+    assert np.max(np.abs(h[:, :1] - c["pt64/sdf"])) < 1e-5 and np.max(np.abs(h[:, 1:] - c["pt64/feat"])) < 5e-5
+    assert np.max(np.abs(m.sdf_network.sdf(x_c).cpu().numpy() - c["pt64/sdf"])) < 1e-5
+    inv_s = m.deviation_network(x)
+    assert tuple(inv_s.shape) == (x.shape[0], 1) and inv_s.requires_grad
+    assert abs(float(inv_s[0, 0]) - float(np.exp(10.0 * float(m.deviation_network.variance)))) < 1e-3
+    with pytest.raises(NotImplementedError):
+        m.color_network(x_c, x_c, x_c, torch.zeros(x.shape[0], 256, device="cuda"))
