@@ -3,6 +3,8 @@
 // SDFNetwork.sdf :788-791), used by hierarchical up-sampling (:92, :281), ray marching (:375), the secant
 // refinement (:435) and mesh extraction (:493).  One launch runs both 9-layer MLPs per 64-point tile with the
 // activations resident in LDS; only 16 B/point are read and 4 B/point written.
+#include <cstdlib>
+
 #include "chain_common.h"
 #include "encode.h"
 #include "launch.h"
@@ -138,7 +140,8 @@ int query_sdf16(const PointSrc& src, const float* packed, const float* weff, flo
 
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out, const int* ray_done) {
-    if (src.M > 0 && src.M <= 8192 && ld_out == 0 && ray_done == nullptr)
+    static const int q16_max = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 8192;      // dev switch
+    if (src.M > 0 && src.M <= q16_max && ld_out == 0 && ray_done == nullptr)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
     static DeviceOnce attr_done;
     if (attr_done.first()) {
