@@ -629,6 +629,14 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
           if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
         return hip_last("point_backward_chains");
     }
+    if (!deform && aux_tail(flags, a.M_color, src.M)) {
+        // no deformation network: sdf_bwd(tail) + colour_bwd(main) | sdf_bwd(main)   (see point_fwd.hip: the tail's tiles ride at the
+        // head of the colour launch instead of adding a third round to the SDF launch; they do not depend on the colour backward)
+        const int Mc = a.M_color;
+        { ScopedTimer tm(KID_COLOR_BWD, Mc, st); if (int e = launch_bwd<BB_SDF, BB_COLOR>(a, (Mp - Mc) / TM, Mc / TM, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        return hip_last("point_backward_chains");
+    }
     if (deform) { ScopedTimer tm(KID_DEFORM_TAN, src.M, st); if (int e = launch_bwd<BB_NONE, BB_TAN>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_BWD, a.M_color, st); if (int e = launch_bwd<BB_NONE, BB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }

@@ -564,6 +564,15 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         { ScopedTimer tm(KID_DEFORM_VJP, Mc, st); if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, Mc / TM, 0, st)) return e; }
         return hip_last("point_forward");
     }
+    if (!deform && aux_tail(flags, a.M_color, src.M)) {
+        // no deformation network (base_d*k1 configs): sdf(main) | sdf(tail) + colour(main).  The main launches are whole rounds of
+        // the 512 workgroup slots; the tail's 48 SDF tiles in the SDF launch would add a third, nearly empty round (+0.6 ms), at the
+        // head of the colour launch they only take 48 slots away from its first two rounds (+0.06 ms)
+        const int Mc = a.M_color;
+        { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_SDF, FB_COLOR>(a, (Mp - Mc) / TM, Mc / TM, Mc / TM, 0, st)) return e; }
+        return hip_last("point_forward");
+    }
     if (deform) { ScopedTimer tm(KID_DEFORM_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mp / 32, 0, st)) return e; }
     { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }

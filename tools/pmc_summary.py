@@ -29,7 +29,7 @@ def agg(d):
 # the chain kernels are instantiations of two dispatcher templates (point_fwd.hip / point_bwd.hip): <B0, B1> = (tail body, main body)
 # body ids: fwd 1 deform (value + J d), 2 sdf, 3 colour, 4 vjp, 5 sdf+vjp (tail); bwd 1 colour, 2 sdf, 3 deform, 4 tan, 5 tan+sdf (tail)
 LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<5, 1>": "k_deform_fwd", "k_point_fwd<0, 2>": "k_sdf_fwd",
-           "k_point_fwd<0, 3>": "k_color_fwd", "k_point_fwd<0, 4>": "k_deform_vjp", "k_point_bwd<0, 1>": "k_color_bwd",
+           "k_point_fwd<0, 3>": "k_color_fwd", "k_point_fwd<2, 3>": "k_color_fwd", "k_point_bwd<2, 1>": "k_color_bwd", "k_point_fwd<0, 4>": "k_deform_vjp", "k_point_bwd<0, 1>": "k_color_bwd",
            "k_point_bwd<0, 2>": "k_sdf_bwd", "k_point_bwd<0, 3>": "k_deform_bwd", "k_point_bwd<5, 3>": "k_deform_bwd",
            "k_point_bwd<0, 4>": "k_deform_tan", "k_wgrad<0>": "k_wgrad[deform]", "k_wgrad<1>": "k_wgrad[sdf]", "k_wgrad<2>": "k_wgrad[color]",
            "k_wgrad<0, false>": "k_wgrad[deform]", "k_wgrad<1, false>": "k_wgrad[sdf]", "k_wgrad<2, false>": "k_wgrad[color]"}

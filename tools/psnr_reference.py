@@ -63,7 +63,17 @@ def psnr(a, b, m):
 
 curve, losses = [], []
 t0 = time.time()
-for it in range(1, n_iter + 1):
+# resumable: the exact training state (parameters, Adam moments, curves) is checkpointed every 50 iterations, so an interrupted
+# run continues on the SAME trajectory (same thread count => same arithmetic)
+CKPT = os.path.join(os.environ.get("PSNR_CKPT_DIR", "/tmp/psnr"), out_name + "_ckpt.pt")
+start = 1
+if os.path.exists(CKPT):
+    ck = torch.load(CKPT, weights_only=False)
+    if ck["n_iter"] == n_iter and ck["n_rays"] == n_rays and ck["dtype"] == str(dtype) and ck["threads"] == threads:
+        r.load_state_dict(ck["model"]); opt.load_state_dict(ck["opt"])
+        curve, losses, start = ck["curve"], ck["losses"], ck["it"] + 1
+        print(f"resumed from iteration {ck['it']}", flush=True)
+for it in range(start, n_iter + 1):
     b = {k: torch.from_numpy(v).to(dtype) for k, v in sched[it - 1].items()}
     for g in opt.param_groups:
         g["lr"] = 5e-4 * lr_factor(it)
@@ -87,6 +97,11 @@ for it in range(1, n_iter + 1):
         curve.append((it, psnr(e["color_map"].numpy(), ev["color"].numpy(), ev["mask"].numpy()),
                       float(((e["depth_map"] - ev["depth"]).abs() * ev["mask"]).sum() / ev["mask"].sum())))
         print(f"it {it:4d} loss {float(loss):.4f} psnr {curve[-1][1]:.3f} depth_l1 {curve[-1][2]:.4f} ({time.time() - t0:.0f}s)", flush=True)
+    if it % 50 == 0:
+        os.makedirs(os.path.dirname(CKPT), exist_ok=True)
+        torch.save(dict(model=r.state_dict(), opt=opt.state_dict(), curve=curve, losses=losses, it=it, n_iter=n_iter, n_rays=n_rays,
+                        dtype=str(dtype), threads=threads), CKPT + ".tmp")
+        os.replace(CKPT + ".tmp", CKPT)
 np.savez(os.path.join(REPO, "tests", "golden", out_name + ".npz"), curve=np.array(curve, np.float64), loss=np.array(losses, np.float64),
          n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11, dtype=str(dtype), threads=threads)
 print("saved")
