@@ -9,7 +9,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O $R/profiles
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline"
+# --headline-only: every launch of the profiled process belongs to the headline workload, so that rocprof's per-symbol averages are
+# directly comparable with roofline.avg_launch_ms of the bench line
+B="python $R/bench.py --no-cpu-baseline --headline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o train -- $B --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmcA -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcB -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
