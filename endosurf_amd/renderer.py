@@ -250,6 +250,9 @@ class EndoSurfNet(nn.Module):
         if new.dtype != torch.float32 or new.device.type != "cuda":
             raise TypeError(f"endosurf_amd parameters live in one fp32 buffer on an AMD GPU (got {new.dtype} on {new.device}); "
                             "the HIP kernels compute in fp32 only")
+        if new.device != self._flat.device:
+            raise RuntimeError(f"an EndoSurfRenderer is bound to the GPU it was constructed on ({self._flat.device}: engine, constant tables, "
+                               f"streams); construct a new one on {new.device} and load_checkpoint(save_checkpoint()) instead of .to()")
         self._flat = new.contiguous()
         self._rebind()
         return self
