@@ -63,6 +63,21 @@ def both_serial():
 
 
 out["secant_then_sampling_serial_ms"] = timed(both_serial)
+# which chain ends last when they run concurrently?  events at the end of each chain, relative to a common start
+torch.cuda.synchronize()
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(30)]
+for e0, e_sec, e_smp in ev:          # host runs ahead (no synchronisation inside the loop), as in the training step
+    e0.record(main)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        r.sample_z(rays, 1)
+        e_smp.record(side)
+    r._march_refine(ms)
+    e_sec.record(main)
+    main.wait_stream(side)
+torch.cuda.synchronize()
+out["concurrent_secant_chain_ends_at_ms"] = sum(e0.elapsed_time(e_sec) for e0, e_sec, _ in ev[5:]) / 25
+out["concurrent_sampling_chain_ends_at_ms"] = sum(e0.elapsed_time(e_smp) for e0, _, e_smp in ev[5:]) / 25
 out["note"] = ("the render forward needs the sampling result; the concurrent figure ~ max(chains) + contention: the secant chain is hidden "
                "whenever it is the shorter of the two")
 print(json.dumps(out, indent=1))
