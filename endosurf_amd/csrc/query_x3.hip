@@ -107,24 +107,45 @@ __global__ __launch_bounds__(256) void k_pack_x3(const float* __restrict__ weff,
 
 // ---- LDS operand planes -------------------------------------------------------------------------------------------------
 // plane p of a K-wide operand: [K/8][PTS points] units of 16 B (8 consecutive k of one point).
-// Two tile shapes: PTS = 64 (8 waves, wave = 32 features x 64 points, 127 KB of LDS: one workgroup per CU) and PTS = 32 (4 waves,
+// Tile shapes: PTS = 64 with 8 waves (wave = 32 features x 64 points; the one the host launches), 16 waves (32 x 32 per wave, four
+// waves per SIMD) or 4 waves (64 x 64 per wave, one per SIMD) -- 127 KB of LDS, one workgroup per CU -- and PTS = 32 (4 waves,
 // wave = 64 features x 32 points, 64 KB: TWO workgroups per CU whose GEMM and epilogue phases interleave on the SIMDs, at twice the
 // weight traffic from L2).  Measured (163 840 points of a training step): 1.90 ms vs 2.70 ms -- the 384 KB of split weights per layer
 // and tile make the short tile L2-bound (62 B/clk/CU at full MFMA rate), so the host launches PTS = 64 (-DX3_PTS=32 builds the other).
+#ifdef X3_PROFILE        // dev builds only (-DX3_PROFILE): cycle stamps of block 0 / wave 0 at the phase boundaries of every layer
+__device__ long long x3_prof[512];
+#define X3_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) x3_prof[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#endif
 #ifndef X3_PTS
 #define X3_PTS 64
 #endif
+// Cycle stamps (-DX3_PROFILE, tools/x3_profile.py) of one 256-wide softplus layer, 8 waves: GEMM 14.5 k cycles for wave 0 + 3.9 k waiting
+// at the barrier for its SIMD partner (12.3 k of MFMA issue for the pair: the GEMM phase is ~66 % efficient), epilogue 4.7 k + 2.4 k
+// waiting for the partner's: 25.6 k per layer, 48 % of it MFMA.  16 waves: the GEMM phase grows to 22.5 k (twice the weight-fragment
+// requests: L1 delivers 64 B/clk hit or miss) -> 2.15 ms instead of 1.89 ms per training step; 4 waves: 26.6 k (one wave per SIMD cannot
+// cover its own operand latencies) -> 2.43 ms.  Requesting the bias values before the GEMM and a rolled (truly prefetching) weight
+// pipeline change nothing (the partner wave already hides those latencies); softplus' exp / log are 0.2 of the 1.9 ms.
+#ifndef X3_WAVES
+#define X3_WAVES (X3_PTS == 64 ? 8 : 4)
+#endif
 template <int PTS>
 struct X3Cfg {
-    static constexpr int PB = PTS / 32;                 // point blocks of a wave tile
-    static constexpr int FB = 2 / PB;                   // feature blocks of a wave tile
-    static constexpr int WAVES = 8 / FB;
+    static constexpr int WAVES = X3_WAVES;              // PTS = 64: 8 or 16;  PTS = 32: 4
+    static constexpr int BLOCKS = 8 * (PTS / 32) / WAVES;   // 32 x 32 output blocks per wave
+    static constexpr int PB = BLOCKS >= 2 && PTS == 64 ? 2 : 1;     // point blocks of a wave tile
+    static constexpr int FB = BLOCKS / PB;                          // feature blocks of a wave tile
+    static constexpr int FGROUPS = 8 / FB;              // waves along the feature axis
     static constexpr int THREADS = WAVES * 64;
     static constexpr int MAIN_PLANE = 32 * PTS * 16;
     static constexpr int ENC_PLANE = 8 * PTS * 16;
-    static constexpr int PARTS = THREADS / PTS;          // 8 thread groups for the per-point VALU stages
-    static constexpr int LDS_BYTES = 3 * MAIN_PLANE + 3 * ENC_PLANE + (4 * PTS + PARTS * 3 * PTS) * 4;
-    static_assert(PARTS == 8, "the per-point stages split k / the encoding items over 8 thread groups");
+    static constexpr int NPARTS = THREADS / PTS < 8 ? THREADS / PTS : 8;      // thread groups (of PTS threads) of the per-point VALU stages
+    static constexpr int VTHREADS = NPARTS * PTS;
+    static constexpr int LDS_BYTES = 3 * MAIN_PLANE + 3 * ENC_PLANE + (4 * PTS + 8 * 3 * PTS) * 4;
+    static_assert(BLOCKS >= 1 && FB * PB == BLOCKS && VTHREADS <= THREADS && NPARTS >= 3, "tile shape");
+    __device__ static int fb0(int wave) { return (wave % FGROUPS) * FB; }
+    __device__ static int pb0(int wave) { return (wave / FGROUPS) * PB; }
 };
 
 template <int PTS>
@@ -151,8 +172,8 @@ template <int KG, int PTS>
 __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[X3Cfg<PTS>::FB][X3Cfg<PTS>::PB], const u32x4* __restrict__ W, const unsigned char* X,
                                         int plane_bytes, int wave, int lane) {
     constexpr int FB = X3Cfg<PTS>::FB, PB = X3Cfg<PTS>::PB;
-    const u32x4* wl = W + (size_t)(wave * FB) * KG * 3 * 64 + lane;
-    const unsigned char* xb = X + ((lane >> 5) * PTS + (lane & 31)) * 16;
+    const u32x4* wl = W + (size_t)X3Cfg<PTS>::fb0(wave) * KG * 3 * 64 + lane;
+    const unsigned char* xb = X + ((lane >> 5) * PTS + 32 * X3Cfg<PTS>::pb0(wave) + (lane & 31)) * 16;
     constexpr int PF = 3;                       // weight fragments in flight: three k-steps ahead (L2 latency)
     u32x4 a[PF + 1][FB][3], b[2][PB][3];
     auto load_a = [&](u32x4(&d)[FB][3], int g) {
@@ -202,7 +223,7 @@ __device__ __forceinline__ void for_quads_x3(f32x16 (&acc)[X3Cfg<PTS>::FB][X3Cfg
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4] = {acc[fi][pb][4 * q + 0], acc[fi][pb][4 * q + 1], acc[fi][pb][4 * q + 2], acc[fi][pb][4 * q + 3]};
-                f(32 * (wave * FB + fi) + 8 * q + 4 * hi, 32 * pb + lo, v);
+                f(32 * (X3Cfg<PTS>::fb0(wave) + fi) + 8 * q + 4 * hi, 32 * (X3Cfg<PTS>::pb0(wave) + pb) + lo, v);
             }
 }
 // store features f0..f0+3 of point p into the three main planes (half of one [k/8][point] unit: ds_write_b64)
@@ -229,13 +250,15 @@ __device__ __forceinline__ void accx_zero(f32x16 (&acc)[FB][PB]) {
 // out[i][p] = sum_k Wrows[i][k] x[p][k] over the 256-wide main planes: 8 thread groups x 32 k each
 template <int NOUT, int PTS>
 __device__ __forceinline__ void smalln_x3(const unsigned char* X, const float* __restrict__ Wrows, float* red, int tid) {
+    if (tid >= X3Cfg<PTS>::VTHREADS) return;
     const int p = tid % PTS, part = tid / PTS;
     float s[NOUT];
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) s[i] = 0.f;
+    constexpr int KP = 256 / X3Cfg<PTS>::NPARTS;
 #pragma unroll 4
-    for (int kk = 0; kk < 32; ++kk) {
-        const int k = 32 * part + kk;
+    for (int kk = 0; kk < KP; ++kk) {
+        const int k = KP * part + kk;
         const float x = get_x3<PTS>(X, X3Cfg<PTS>::MAIN_PLANE, k, p);
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) s[i] = fmaf(Wrows[i * 256 + k], x, s[i]);
@@ -247,35 +270,37 @@ template <int NOUT, int PTS>
 __device__ __forceinline__ float smalln_x3_reduce(const float* red, int i, int p) {
     float s = 0.f;
 #pragma unroll
-    for (int part = 0; part < 8; ++part) s += red[(part * NOUT + i) * PTS + p];
+    for (int part = 0; part < X3Cfg<PTS>::NPARTS; ++part) s += red[(part * NOUT + i) * PTS + p];
     return s;
 }
 
 template <int L, int PTS>
 __device__ __forceinline__ void encode3_x3(unsigned char* E, int kbase, const float* px, int tid) {
+    if (tid >= X3Cfg<PTS>::VTHREADS) return;
     const int p = tid % PTS, part = tid / PTS;
-    for (int item = part; item < 3 * L; item += 8) {
+    for (int item = part; item < 3 * L; item += X3Cfg<PTS>::NPARTS) {
         const int c = item % 3, i = item / 3;
         float s, co;
         sincosf(px[c * PTS + p] * (float)(1 << i), &s, &co);
         put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(3, i, 0, c), p, s);
         put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(3, i, 1, c), p, co);
     }
-    if (part == 7) {
+    if (part == X3Cfg<PTS>::NPARTS - 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + c, p, px[c * PTS + p]);
     }
 }
 template <int L, int PTS>
 __device__ __forceinline__ void encode1_x3(unsigned char* E, int kbase, const float* pt, int tid) {
+    if (tid >= X3Cfg<PTS>::VTHREADS) return;
     const int p = tid % PTS, part = tid / PTS;
-    for (int i = part; i < L; i += 8) {
+    for (int i = part; i < L; i += X3Cfg<PTS>::NPARTS) {
         float s, co;
         sincosf(pt[p] * (float)(1 << i), &s, &co);
         put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(1, i, 0, 0), p, s);
         put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase + enc_index(1, i, 1, 0), p, co);
     }
-    if (part == 6) put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase, p, pt[p]);
+    if (part == X3Cfg<PTS>::NPARTS - 2) put_x3<PTS>(E, X3Cfg<PTS>::ENC_PLANE, kbase, p, pt[p]);
 }
 template <int PTS>
 __device__ __forceinline__ void zero_enc_x3(unsigned char* E, int tid) {       // all three encoding planes (padding k must read as 0)
@@ -304,6 +329,7 @@ __global__ __launch_bounds__(X3Cfg<PTS>::THREADS, 1) void k_query_sdf_x3(PointSr
         for (int r = r_first; r <= r_last; ++r) all_done = all_done && ray_done[r] != 0;
         if (all_done) return;       // workgroup-uniform
     }
+    X3_STAMP(0);
     if (tid < PTS) {
         float x[3], t, d[3];
         load_point(src, row0 + tid, x, t, d);
@@ -383,17 +409,22 @@ __global__ __launch_bounds__(X3Cfg<PTS>::THREADS, 1) void k_query_sdf_x3(PointSr
         accx_zero(acc);
         // X3_SEGS order: ..., SF3, SF4M, SF4A, SF5, ...
         const int si = X3_SF0 + (l <= 4 ? l : l + 1);
+        X3_STAMP(100 + 4 * l);
         gemm_x3<16, PTS>(acc, W(si), X, MAIN_PLANE, wave, lane);
         if (l == 4) gemm_x3<3, PTS>(acc, W(X3_SF4A), E, ENC_PLANE, wave, lane);   // NeRF skip: + encoding part
+        X3_STAMP(101 + 4 * l);
         __syncthreads();
+        X3_STAMP(102 + 4 * l);
         const float* bias = weff + tb.boff[NET_S * LAYERS + l];
         for_quads_x3<PTS>(acc, wave, lane, [&](int f0, int p, float(&v)[4]) {
             const float4 b = bias4(bias, f0);
             v[0] = softplus100(v[0] + b.x); v[1] = softplus100(v[1] + b.y); v[2] = softplus100(v[2] + b.z); v[3] = softplus100(v[3] + b.w);
             store_quad_x3<PTS>(X, f0, p, v);
         });
+        X3_STAMP(103 + 4 * l);
         __syncthreads();
     }
+    X3_STAMP(140);
     smalln_x3<1, PTS>(X, weff + tb.woff[NET_S * LAYERS + 8], red, tid);
     __syncthreads();
     if (tid < PTS && row0 + tid < src.M) {
@@ -403,6 +434,11 @@ __global__ __launch_bounds__(X3Cfg<PTS>::THREADS, 1) void k_query_sdf_x3(PointSr
     }
 }
 
+#ifdef X3_PROFILE
+extern "C" int es_debug_x3_profile(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(x3_prof), sizeof(long long) * (n < 512 ? n : 512));
+}
+#endif
 size_t packed_x3_bytes() { return X3_UNITS * 16; }
 
 int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st) {

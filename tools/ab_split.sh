@@ -2,7 +2,7 @@
 # Dev tool: A/B two builds of the library in split-precision mode on the same GPU box.  usage: bash tools/ab_split.sh [rounds]
 L=endosurf_amd/lib
 for r in $(seq ${1:-2}); do
-  for v in A B; do
+  for v in ${VARIANTS:-A B}; do
     cp $L/variant_$v.so $L/libendosurf_hip.so
     python bench.py --no-cpu-baseline --split-precision --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys
