@@ -13,6 +13,14 @@
 
 namespace es {
 
+#ifdef ES_PROFILE_QUERY      // dev builds only: cycle stamps of block 0 / thread 0 at the phase boundaries (tools/q_profile.py)
+__device__ long long q_prof[64];
+#define Q_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) q_prof[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int es_debug_q_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_prof), sizeof(long long) * (n < 64 ? n : 64)); }
+#else
+#define Q_STAMP(i) do {} while (0)
+#endif
+
 // HALF: latency-bound small batches (secant iterations, 8-sample up-sampling queries) use 32-point tiles: the LDS tile keeps
 // its 64-row layout but only row-tile 0 carries points, so every layer issues half the MFMAs and twice as many workgroups
 // share the batch.
@@ -39,6 +47,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
         if (all_done) return;       // workgroup-uniform
     }
 
+    Q_STAMP(0);
     if (tid < 64) {
         float x[3], t, d[3];
         load_point(src, tid < PTS ? row0 + tid : src.M, x, t, d);
@@ -52,6 +61,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
         encode1<6>(aux, 39, pt, tid);
         zero_rows(aux, 52, 56, tid);
         __syncthreads();
+        Q_STAMP(1);
         {
             f32x16 acc[RTC][2];
             acc_zero(acc);
@@ -65,11 +75,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
             });
         }
         __syncthreads();
+        Q_STAMP(2);
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             f32x16 acc[RTC][2];
             acc_zero(acc);
+            Q_STAMP(10 + l);
             gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[DF0 + l], 0, 2 * wave, lane);
+            Q_STAMP(20 + l);
             __syncthreads();
             const float* bias = weff + tb.boff[NET_D * LAYERS + l];
             for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
             });
             __syncthreads();
         }
+        Q_STAMP(3);
         smalln_partial<3>(mainT, weff + tb.woff[NET_D * LAYERS + 8], 256, red, tid);
         __syncthreads();
         if (tid < 192) {
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     }
 
     // ---- SDF MLP on x_c, output column 0 only ----
+    Q_STAMP(4);
     encode3<6>(aux, 0, px, tid);
     zero_rows(aux, 39, 40, tid);
     __syncthreads();
@@ -110,10 +125,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
         });
     }
     __syncthreads();
+    Q_STAMP(5);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x16 acc[RTC][2];
         acc_zero(acc);
+        Q_STAMP(30 + l);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
         gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, RTC, 2>(acc, aux, packed + tb.segoff[SF4A], 0, 2 * wave, lane);   // NeRF skip: + enc part
@@ -127,8 +144,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
         });
         __syncthreads();
     }
+    Q_STAMP(6);
     smalln_partial<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
     __syncthreads();
+    Q_STAMP(7);
     if (tid < PTS && row0 + tid < src.M) {
         const int i = row0 + tid;
         const size_t o = ld_out > 0 ? (size_t)(i / src.n_per_ray) * ld_out + (i % src.n_per_ray) : (size_t)i;   // [ray][ld_out] or flat
