@@ -20,6 +20,14 @@
 
 namespace es {
 
+#ifdef ES_PROFILE_BWD        // dev builds only: cycle stamps of block 0 / thread 0 inside sdf_bwd_tile (tools/bwd_profile.py)
+__device__ long long b_prof[256];
+#define B_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) b_prof[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int es_debug_b_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(b_prof), sizeof(long long) * (n < 256 ? n : 256)); }
+#else
+#define B_STAMP(i) do {} while (0)
+#endif
+
 struct BwdArgs {
     PointSrc src;
     Tabs tb;
@@ -234,6 +242,7 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = tile * TM;
     const size_t grow0 = (size_t)row0;
+    B_STAMP(200);
     const bool deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
     const size_t Mp = (size_t)a.L.Mp;
 
@@ -313,10 +322,14 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
+        B_STAMP(4 * l);
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
+        B_STAMP(4 * l + 1);
         __syncthreads();
+        B_STAMP(4 * l + 2);
         epi_t(acc, l);
+        B_STAMP(4 * l + 3);
         __syncthreads();
     }
     // ---- (ii) reverse sweep of the value pass, seeded with zbar_8 = [sdfbar | featbar] ----
@@ -364,16 +377,20 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
         f32x16 acc[2][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
+        B_STAMP(100 + 4 * l);
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         f32x16 accA[1][1];
         if (l == 4) {
             acc_zero(accA);
             gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);
         }
+        B_STAMP(100 + 4 * l + 1);
         __syncthreads();
+        B_STAMP(100 + 4 * l + 2);
         epi_b(acc, l);
         if (l == 4)
             for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
+        B_STAMP(100 + 4 * l + 3);
         __syncthreads();
     }
     {
@@ -406,6 +423,7 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) xb[j] = tx[j * 64 + tid] + (color ? wsb(a, WS_XCBAR_C)[gp * 3 + j] : 0.f);
     }
+    B_STAMP(201);
 }
 
 // -------------------------------------------------------------------------------------------------------------
