@@ -2,11 +2,12 @@
 of the REFERENCE renderer trained on CPU (tools/psnr_reference.py) with the same initial weights, batches and random draws, through
 the steep part and onto the PLATEAU of a complete schedule (1500 iterations, warm-up + cosine decay to 5 %).
 
-What "matched" can mean is bounded by the reference itself: training is chaotic, and two fp32 runs of the reference that differ only
-in the intra-op thread count (another GEMM summation order; tests/golden/psnr_reference_long.npz vs psnr_reference_t3.npz) drift
-apart by several dB at single evaluation points of the steep phase and re-converge on the plateau.  The test therefore asserts
+What "matched" can mean is bounded by the reference itself: training is chaotic, and fp32 runs of the reference that differ only in
+the intra-op thread count (another GEMM summation order; tests/golden/psnr_reference_long.npz = 4 threads, psnr_reference_t*.npz =
+other counts) drift apart by up to 8 dB at single evaluation points of the steep phase and still end ~2 dB apart on the plateau.
+The test therefore asserts
   (1) the same start and the same early trajectory (before rounding differences have been amplified);
-  (2) the plateau (mean of the last evaluations) within max(0.5 dB, 2x the reference's own run-to-run difference there);
+  (2) the plateau (mean of the last evaluations) inside the BAND spanned by the reference's own runs, widened by 0.5 dB;
   (3) the same final loss level.
 The HIP run uses the deterministic reduction mode, so it is itself bit-reproducible (tests/test_gpu_determinism.py)."""
 import os
@@ -21,8 +22,24 @@ from gpu_util import renderer_for
 pytestmark = pytest.mark.gpu
 GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = os.path.join(GOLD_DIR, "psnr_reference_long.npz")
-GOLD_B = os.path.join(GOLD_DIR, "psnr_reference_t3.npz")
 N_TAIL = 4          # evaluations averaged on the plateau (iterations 1350..1500)
+MARGIN_DB = 0.5
+
+
+def _reference_runs():
+    """Every committed run of the reference on this schedule: {name: curve}; the 4-thread run first."""
+    import glob
+    runs = {"psnr_reference_long": np.load(GOLD)["curve"]}
+    for f in sorted(glob.glob(os.path.join(GOLD_DIR, "psnr_reference_t*.npz"))):
+        c = np.load(f)["curve"]
+        if len(c) == len(runs["psnr_reference_long"]):
+            runs[os.path.basename(f)[:-4]] = c
+    return runs
+
+
+def _plateau_band(runs):
+    ends = [float(np.mean(c[-N_TAIL:, 1])) for c in runs.values()]
+    return min(ends) - MARGIN_DB, max(ends) + MARGIN_DB, ends
 
 
 def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False):
@@ -55,27 +72,21 @@ def test_psnr_curve_matches_reference_to_the_plateau():
     curve, losses = _train(n_iter, n_rays, int(g["weight_seed"]), int(g["sched_seed"]), ref_curve[:, 0])
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    extra = {}
-    # the reference's own run-to-run difference (same code, same inputs, another thread count)
-    spread_tail, spread_max = 0.0, None
-    if os.path.exists(GOLD_B):
-        gb = np.load(GOLD_B)
-        n = min(len(gb["curve"]), len(ref_curve))
-        if n == len(ref_curve):
-            spread_tail = abs(float(np.mean(gb["curve"][-N_TAIL:, 1]) - np.mean(ref_curve[-N_TAIL:, 1])))
-        spread_max = float(np.max(np.abs(gb["curve"][:n, 1] - ref_curve[:n, 1])))
-        extra = dict(ref_b_curve=gb["curve"], ref_b_loss=gb["loss"])
-    np.savez(os.path.join(out, "psnr_hip.npz"), curve=curve, loss=losses, ref_curve=ref_curve, ref_loss=ref_loss, **extra)
+    runs = _reference_runs()
+    lo, hi, ends = _plateau_band(runs)
+    others = [c for k, c in runs.items() if k != "psnr_reference_long"]
+    spread_max = max([float(np.max(np.abs(c[:, 1] - ref_curve[:, 1]))) for c in others], default=None)
+    np.savez(os.path.join(out, "psnr_hip.npz"), curve=curve, loss=losses, ref_curve=ref_curve, ref_loss=ref_loss,
+             **{f"ref_{k}": c for k, c in runs.items()})
     assert np.array_equal(curve[:, 0], ref_curve[:, 0])
     d = curve[:, 1] - ref_curve[:, 1]
     # (1) identical start (same weights) and the same early trajectory (iterations 1..60)
     assert abs(d[0]) < 0.02, d[0]
     early = ref_curve[:, 0] <= 60
     assert np.max(np.abs(d[early])) < 0.1, d[early]
-    # (2) the plateau: within max(0.5 dB, 2x the reference's own run-to-run difference)
-    end, ref_end = float(np.mean(curve[-N_TAIL:, 1])), float(np.mean(ref_curve[-N_TAIL:, 1]))
-    tol = max(0.5, 2.0 * spread_tail)
-    assert abs(end - ref_end) < tol, (end, ref_end, tol, spread_tail, spread_max)
+    # (2) the plateau: inside the band of the reference's own runs (+- 0.5 dB)
+    end = float(np.mean(curve[-N_TAIL:, 1]))
+    assert lo < end < hi, (end, lo, hi, ends)
     assert end > curve[0, 1] + 15.0, "training must reach the reference's quality level"
     # in between the curves may only differ as much as the reference differs from itself (+ margin)
     if spread_max is not None:
@@ -104,10 +115,6 @@ def test_psnr_plateau_in_split_precision_mode():
     np.savez(os.path.join(out, "psnr_hip_split.npz"), curve=curve, loss=losses)
     d = curve[:, 1] - ref_curve[:, 1]
     assert abs(d[0]) < 0.02 and np.max(np.abs(d[ref_curve[:, 0] <= 60])) < 0.1
-    spread_tail = 0.0
-    if os.path.exists(GOLD_B):
-        gb = np.load(GOLD_B)
-        if len(gb["curve"]) == len(ref_curve):
-            spread_tail = abs(float(np.mean(gb["curve"][-N_TAIL:, 1]) - np.mean(ref_curve[-N_TAIL:, 1])))
-    end, ref_end = float(np.mean(curve[-N_TAIL:, 1])), float(np.mean(ref_curve[-N_TAIL:, 1]))
-    assert abs(end - ref_end) < max(0.5, 2.0 * spread_tail), (end, ref_end, spread_tail)
+    lo, hi, ends = _plateau_band(_reference_runs())
+    end = float(np.mean(curve[-N_TAIL:, 1]))
+    assert lo < end < hi, (end, lo, hi, ends)

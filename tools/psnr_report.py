@@ -10,9 +10,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(REPO, "tests", "golden")
 O = os.path.join(REPO, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
 ref = np.load(os.path.join(G, "psnr_reference_long.npz"))["curve"]
+import glob
 cols = {"reference fp32 (4 threads)": ref}
-for name, path in (("reference fp32 (3 threads)", os.path.join(G, "psnr_reference_t3.npz")), ("HIP fp32 (deterministic)", os.path.join(O, "psnr_hip.npz")),
-                   ("HIP split precision", os.path.join(O, "psnr_hip_split.npz"))):
+extra = [(f"reference fp32 ({os.path.basename(f)[16:-4]} threads)", f) for f in sorted(glob.glob(os.path.join(G, "psnr_reference_t*.npz")))]
+for name, path in extra + [("HIP fp32 (deterministic)", os.path.join(O, "psnr_hip.npz")), ("HIP split precision", os.path.join(O, "psnr_hip_split.npz"))]:
     if os.path.exists(path):
         cols[name] = np.load(path)["curve"]
 its = [1, 30, 60, 100, 150, 200, 250, 300, 400, 500, 600, 800, 1000, 1200, 1350, 1400, 1450, 1500]
