@@ -7,7 +7,9 @@ the intra-op thread count (another GEMM summation order; tests/golden/psnr_refer
 other counts) drift apart by up to 8 dB at single evaluation points of the steep phase and still end ~2 dB apart on the plateau.
 The test therefore asserts
   (1) the same start and the same early trajectory (before rounding differences have been amplified);
-  (2) the plateau (mean of the last evaluations) inside the BAND spanned by the reference's own runs, widened by 0.5 dB;
+  (2) the plateau (mean of the last evaluations) within max(0.5 dB, 2.5 sample standard deviations) of the mean plateau of the
+      reference's own runs -- a new run of the REFERENCE lands outside the [min, max] of n earlier runs with probability 2 / (n + 1),
+      so the band itself would be a flaky criterion even for the reference;
   (3) the same final loss level.
 The HIP run uses the deterministic reduction mode, so it is itself bit-reproducible (tests/test_gpu_determinism.py)."""
 import os
@@ -38,8 +40,10 @@ def _reference_runs():
 
 
 def _plateau_band(runs):
+    """(lo, hi, plateau values): mean of the reference runs' plateaus +- max(0.5 dB, 2.5 x their sample standard deviation)."""
     ends = [float(np.mean(c[-N_TAIL:, 1])) for c in runs.values()]
-    return min(ends) - MARGIN_DB, max(ends) + MARGIN_DB, ends
+    tol = max(MARGIN_DB, 2.5 * float(np.std(ends, ddof=1))) if len(ends) > 1 else MARGIN_DB
+    return float(np.mean(ends)) - tol, float(np.mean(ends)) + tol, ends
 
 
 def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False):
@@ -84,7 +88,7 @@ def test_psnr_curve_matches_reference_to_the_plateau():
     assert abs(d[0]) < 0.02, d[0]
     early = ref_curve[:, 0] <= 60
     assert np.max(np.abs(d[early])) < 0.1, d[early]
-    # (2) the plateau: inside the band of the reference's own runs (+- 0.5 dB)
+    # (2) the plateau: within the reference's own run-to-run variability of its mean plateau
     end = float(np.mean(curve[-N_TAIL:, 1]))
     assert lo < end < hi, (end, lo, hi, ends)
     assert end > curve[0, 1] + 15.0, "training must reach the reference's quality level"
