@@ -19,6 +19,14 @@
 
 namespace es {
 
+#ifdef ES_PROFILE_WGRAD       // dev builds only: cycle stamps of block 0 / thread 0 inside the fp32 task (tools/wgrad_profile.py)
+__device__ long long w_prof[128];
+#define W_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) w_prof[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int es_debug_w_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w_prof), sizeof(long long) * (n < 128 ? n : 128)); }
+#else
+#define W_STAMP(i) do {} while (0)
+#endif
+
 constexpr int WG_MAX_PROBS = 20;
 
 struct WgProb {
@@ -170,16 +178,29 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     WG_SSTORE(p0, 0);
     __syncthreads();
 #pragma unroll 1
+    W_STAMP(0);
     for (int st = 0; st < nst; st += 2) {
+        const bool stamp = st == 32;                     // one iteration in the steady state
+        if (stamp) W_STAMP(1);
         if (st + 2 < nst) WG_GLOAD(p0, m0 + WG_R * (st + 2));
         compute(0);
+        if (stamp) W_STAMP(2);
         WG_SSTORE(p1, 1);                                // stage st+1 (loaded one iteration ago)
+        if (stamp) W_STAMP(3);
         __syncthreads();
+        if (stamp) W_STAMP(4);
         if (st + 3 < nst) WG_GLOAD(p1, m0 + WG_R * (st + 3));
         compute(1);
+        if (stamp) W_STAMP(5);
         if (st + 2 < nst) WG_SSTORE(p0, 0);              // stage st+2
+        if (stamp) W_STAMP(6);
         __syncthreads();
+        if (stamp) W_STAMP(7);
     }
+    W_STAMP(8);
+#ifdef ES_PROFILE_WGRAD
+    if (blockIdx.x == 0 && threadIdx.x == 0) w_prof[20] = nst;
+#endif
 #undef WG_GLOAD
 #undef WG_SSTORE
     // acc[t][tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*128 + kh*64 + 2*lo + tp
@@ -212,6 +233,7 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
             else if (tid < P.N) atomicAdd(P.bias_out + tid, s);
         }
     }
+    W_STAMP(9);
 }
 
 // Slice `slot` of `nslots` of a small problem: thread = (input feature k, row-block parity); 16-row blocks, the loads of two
