@@ -86,9 +86,11 @@ def test_split_precision_training_step_matches_fp32():
         res.append((z, d_i, float(total)))
     (z0, d0, l0), (z1, d1, l1) = res
     # inverse-CDF sampling and the secant iteration amplify rounding differences of the SDF (the reference's own fp32-vs-fp64 sample
-    # depths differ by up to ~1e-2 at isolated samples, tests/golden z_trace vs z_trace64): quantile + loose max, like test_gpu_rays.py
+    # depths differ by up to ~1e-2 at isolated samples, tests/golden z_trace vs z_trace64; a sample in a flat stretch of the cdf can move by
+    # a whole coarse bin, (far - near) / 32 ~ 0.06): quantile + a handful of outliers + bin-width bound, like test_gpu_rays.py
     dz = (z0 - z1).abs().flatten()
-    assert float(torch.quantile(dz, 0.99)) < 2e-5 and float(dz.max()) < 2e-2, (float(torch.quantile(dz, 0.99)), float(dz.max()))
+    q99, n_out, dmax = float(torch.quantile(dz, 0.99)), int((dz > 1e-3).sum()), float(dz.max())
+    assert q99 < 2e-5 and n_out <= 8 and dmax < 0.1, (q99, n_out, dmax)
     fin = torch.isfinite(d0) & torch.isfinite(d1)
     assert torch.equal(torch.isfinite(d0), torch.isfinite(d1)) and float((d0[fin] - d1[fin]).abs().max()) < 2e-4
     assert abs(l0 - l1) < 1e-3 * max(1.0, abs(l0))
