@@ -1,0 +1,166 @@
+// Core of the register-resident split-precision kernels (query_x3r.hip, infer_x3r.hip): the k-step-ordered weight stream, the
+// operand fragments and the GEMM of one layer.  See query_x3r.hip for the formulation.
+#pragma once
+#include "chain_common.h"
+#include "x3_common.h"
+
+namespace es {
+
+// segments in the order the kernels walk them: [0, 8) deformation forward, [8, 17) SDF forward (query_x3r.hip, infer_x3r.hip value
+// passes), [17, 25) deformation reverse DR7 .. DR0 (the VJP sweep of infer_x3r.hip)
+constexpr int XR_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7,
+                           DR7, DR6, DR5, DR4, DR3, DR2, DR1, DR0};
+constexpr int XR_COUNT = sizeof(XR_SEGS) / sizeof(int);
+constexpr int xr_kg(int i) { return 2 * cdiv(SEGS[XR_SEGS[i]].kreal, 32); }      // k-steps, even (the stream works in pairs)
+constexpr int xr_chunk0(int i) {
+    int c = 0;
+    for (int k = 0; k < i; ++k) c += xr_kg(k);
+    return c;
+}
+constexpr int XR_CHUNKS = xr_chunk0(XR_COUNT);
+constexpr int XR_PAD_CHUNKS = 4;                          // a stream reads up to 3 k-steps past its end
+constexpr int XR_SDF_CHUNK0 = xr_chunk0(8);               // first k-step of SF0
+constexpr int XR_QUERY_CHUNKS = xr_chunk0(17);            // 236: end of the query stream
+constexpr int XR_DR_CHUNK0 = xr_chunk0(17);               // first k-step of DR7
+constexpr int XR_CHUNK_UNITS = 8 * 3;                     // 1 KB units (64 lanes x 16 B) per k-step
+constexpr int XR_CHUNK_BYTES = XR_CHUNK_UNITS * 1024;
+constexpr int XR_THREADS = 256;
+constexpr int XR_ENC_LD = 68;                             // floats per column row of the encoding scratch (conflict-free b32 / b128 reads)
+constexpr int XR_RING = 4;                                // k-steps resident in LDS
+static_assert(XR_SDF_CHUNK0 % 2 == 0 && XR_DR_CHUNK0 % 2 == 0 && XR_CHUNKS % 2 == 0, "k-step pairs");
+static_assert(LAYER_N[NET_D][3] == 204 && LAYER_N[NET_S][7] == 256 && SEGS[SF4A].kreal == 39, "shapes the kernels hard-code");
+
+// position j (0..7) of lane half hi in k-step-local order -> k offset inside the 16-wide step
+__host__ __device__ constexpr int xr_kperm(int hi, int j) { return j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4); }
+
+// ---- the weight stream -----------------------------------------------------------------------------------------------------------
+// K-step k lives in ring slot k % 4; k-steps travel in pairs (2c, 2c+1).  Every wave moves 6 of the 24 1-KB units of a k-step by
+// direct loads.  The timeline, with each k-step split into its two accumulator groups:
+//     k-step 2c,   group 0:  read the fragments of (2c, group 1);    MFMAs, with the 6 pieces of k-step 2c+2 issued between them
+//     k-step 2c,   group 1:  read the fragments of (2c+1, group 0);  MFMAs, with the 6 pieces of k-step 2c+3 issued between them
+//     k-step 2c+1, group 0:  read the fragments of (2c+1, group 1);  MFMAs;  all pieces landed (vmcnt 0), BARRIER
+//     k-step 2c+1, group 1:  read the fragments of (2c+2, group 0);  MFMAs
+// A pair's slots are rewritten one barrier after their last read and read one barrier after they landed; the fragments needed right
+// after a barrier are requested before the MFMAs that follow it.  A bare s_barrier + explicit vmcnt: nothing else is in flight.
+struct FragA { u32x4 p[4][3]; };
+struct WStream {
+    const u32x4* g;          // k-step 0
+    unsigned char* ring;
+    int k, wave, lane;       // k = the k-step being computed
+    FragA a0;                // fragments of (k, group 0), read ahead
+    __device__ __forceinline__ void piece(int kk, int i) {
+#ifndef XR_NO_DMA
+        const u32x4* src = g + ((size_t)kk * XR_CHUNK_UNITS + wave * 6 + i) * 64 + lane;
+        unsigned char* dst = ring + (kk & (XR_RING - 1)) * XR_CHUNK_BYTES + (wave * 6 + i) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+    }
+    __device__ __forceinline__ void landed_barrier() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef XR_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+    }
+    __device__ __forceinline__ void read_group(FragA& a, int kk, int grp) const {
+        const u32x4* A = reinterpret_cast<const u32x4*>(ring + (kk & (XR_RING - 1)) * XR_CHUNK_BYTES) + lane;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a.p[f][p] = A[((4 * grp + f) * 3 + p) * 64];
+    }
+    __device__ __forceinline__ void start() {      // no other vector-memory operation may be outstanding while the stream runs
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { piece(k, i); piece(k + 1, i); }
+        landed_barrier();
+        read_group(a0, k, 0);
+    }
+};
+
+#ifdef XR_PROFILE        // dev builds only (tools/xr_profile.sh): cycle stamps of block 0 / wave 0
+extern __device__ long long xr_prof[512];
+#define XR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) xr_prof[i] = __builtin_readcyclecounter(); } while (0)
+#define XR_ADD(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) xr_prof[i] += (v); } while (0)
+#else
+#define XR_STAMP(i) do {} while (0)
+#define XR_ADD(i, v) do {} while (0)
+#endif
+
+struct FragB { u32x4 h, m, l; };
+template <class VAL>
+__device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hh, mm, ll;
+        split_pair(val(s, 2 * j), val(s, 2 * j + 1), hh, mm, ll);
+        b.h[j] = hh; b.m[j] = mm; b.l[j] = ll;
+    }
+}
+
+// C[fb] += W[32 fb .. +31][k-steps 0 .. KG) . B, with B's k-step s operand = split(val(s, 0..7)); the operand of k-step s+1 is built
+// between the MFMAs of k-step s.  MFMA order: term-major over groups of 4 accumulators -- consecutive MFMAs never share an
+// accumulator (an instruction issued between two MFMAs of one accumulate chain costs ~40 cycles, between independent ones ~6), the
+// six partial products of an accumulator still arrive smallest first.  KG is even and ws.k is even on entry.
+template <int G, class VAL>
+__device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const FragA& a, const FragB& b, FragB& nb, float (&v)[8], VAL&& val, int snext,
+                                           bool more, bool stage) {
+    // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
+    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const u32x4 bt = TB[t] == 0 ? b.h : (TB[t] == 1 ? b.m : b.l);
+#ifndef XR_NO_MFMA
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            C[4 * G + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[f][TA[t]]), __builtin_bit_cast(bf16x8, bt),
+                                                                  C[4 * G + f], 0, 0, 0);
+#endif
+        if (stage) ws.piece(ws.k + 2 + G, t);     // one direct load per four MFMAs
+#ifndef XR_NO_VALU
+        const int k = 4 * G + t;                  // 8 of the 12 (group, term) slots build one value each
+        if (more && t < 4) {
+            v[k] = val(snext, k);
+            if (k & 1) {
+                unsigned hh, mm, ll;
+                split_pair(v[k - 1], v[k], hh, mm, ll);
+                nb.h[k >> 1] = hh; nb.m[k >> 1] = mm; nb.l[k >> 1] = ll;
+            }
+        }
+#endif
+    }
+}
+template <int KG, class VAL>
+__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) {
+    static_assert(KG % 2 == 0, "k-step pairs");
+    FragB b;
+    build_frag(b, val, 0);
+#pragma unroll
+    for (int s = 0; s < KG; ++s) {
+        FragB nb = b;
+        float v[8];
+        FragA a1;
+        ws.read_group(a1, ws.k, 1);
+        mfma_group<0>(C, ws, ws.a0, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        if (s & 1) ws.landed_barrier();
+        ws.read_group(ws.a0, ws.k + 1, 0);
+        mfma_group<1>(C, ws, a1, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        b = nb;
+        ++ws.k;
+    }
+}
+
+// accumulators start from the layer's bias: register 4 q + i of block b is feature 32 b + 8 q + 4 hi + i
+__device__ __forceinline__ void init8(f32x16 (&C)[8], const float* bl, int hi) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(bl + 32 * b + 8 * q + 4 * hi);
+            C[b][4 * q] = v.x; C[b][4 * q + 1] = v.y; C[b][4 * q + 2] = v.z; C[b][4 * q + 3] = v.w;
+        }
+}
+__device__ __forceinline__ void copy8(f32x16 (&P)[8], const f32x16 (&C)[8]) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) P[b] = C[b];
+}
+
+}  // namespace es
