@@ -29,7 +29,7 @@ class es_composite_args(C.Structure):
 
 
 class es_render_args(C.Structure):
-    _fields_ = [("c", es_composite_args), ("ws", C.c_void_p), ("scratch", C.c_void_p), ("flags", C.c_int), ("wg_scratch", C.c_void_p)]
+    _fields_ = [("c", es_composite_args), ("ws", C.c_void_p), ("scratch", C.c_void_p), ("flags", C.c_int), ("wg_scratch", C.c_void_p), ("packed_x3", C.c_void_p)]
 
 
 class es_loss_args(C.Structure):
@@ -75,6 +75,7 @@ PROTOTYPES = {
     "es_point_workspace_floats": (C.c_int64, [_I, _I]),
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
+    "es_point_forward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "es_wgrad_scratch_floats": (C.c_int64, []),
     "es_point_backward_det": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -96,7 +97,7 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 

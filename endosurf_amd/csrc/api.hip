@@ -20,7 +20,8 @@ int query_sdf_x3(const PointSrc& src, const void* packed_x3, const float* weff, 
                  const int* ray_done);
 int variance_terms(const float* variance, const float* d_invs_acc, float* s_val, float* d_var, hipStream_t st);
 
-int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st);
+int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st,
+                  const void* packed_x3 = nullptr);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
@@ -222,6 +223,15 @@ int es_point_forward(const es_points* pts, const float* packed, const float* wef
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     return point_forward(to_src(pts), packed, weff, ws, flags, m_color, (hipStream_t)stream);
 }
+int es_point_forward_x3(const es_points* pts, const float* packed, const void* packed_x3, const float* weff, float* ws, int flags, int m_color,
+                        void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && packed_x3 && weff && (ws || pts->M == 0), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_SAVE), "es_point_forward_x3 is the no-grad evaluation (no ES_PF_SAVE)");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    return point_forward(to_src(pts), packed, weff, ws, flags | ES_PF_X3, m_color, (hipStream_t)stream, packed_x3);
+}
 
 int es_point_backward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
                       const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, void* stream) {
@@ -348,7 +358,7 @@ int es_render_forward(const es_render_args* a, const float* packed, const float*
     if (a->c.N == 0) return ST_OK;
     hipStream_t st = (hipStream_t)stream;
     if (int e = mid_z(a->c.z, a->c.ldz, a->c.N, a->c.S, a->c.sample_dist, a->scratch, st)) return e;
-    if (int e = point_forward(ps, packed, weff, a->ws, flags, 0, st)) return e;
+    if (int e = point_forward(ps, packed, weff, a->ws, flags, 0, st, a->packed_x3)) return e;
     return composite(render_composite_args(a, flags), 0, st);
 }
 int es_render_backward(const es_render_args* a, const float* packed, const float* weff, float* dweff, void* stream) {

@@ -243,6 +243,7 @@ static bool use_x3r() {      // ES_X3R=0: the LDS-resident kernel of this file (
     return v;
 }
 size_t packed_x3_bytes() { return X3_UNITS * 16 + packed_x3r_bytes(); }
+const void* packed_x3r_part(const void* packed_x3) { return static_cast<const unsigned char*>(packed_x3) + X3_UNITS * 16; }
 
 int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st) {
     if (int e = init_tables()) return e;

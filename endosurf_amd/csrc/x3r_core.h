@@ -100,7 +100,7 @@ __device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s) {
 // between the MFMAs of k-step s.  MFMA order: term-major over groups of 4 accumulators -- consecutive MFMAs never share an
 // accumulator (an instruction issued between two MFMAs of one accumulate chain costs ~40 cycles, between independent ones ~6), the
 // six partial products of an accumulator still arrive smallest first.  KG is even and ws.k is even on entry.
-template <int G, class VAL>
+template <int G, bool MFMA, class VAL>
 __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const FragA& a, const FragB& b, FragB& nb, float (&v)[8], VAL&& val, int snext,
                                            bool more, bool stage) {
     // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
@@ -109,10 +109,11 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
     for (int t = 0; t < 6; ++t) {
         const u32x4 bt = TB[t] == 0 ? b.h : (TB[t] == 1 ? b.m : b.l);
 #ifndef XR_NO_MFMA
+        if (MFMA)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-            C[4 * G + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[f][TA[t]]), __builtin_bit_cast(bf16x8, bt),
-                                                                  C[4 * G + f], 0, 0, 0);
+            for (int f = 0; f < 4; ++f)
+                C[4 * G + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[f][TA[t]]), __builtin_bit_cast(bf16x8, bt),
+                                                                      C[4 * G + f], 0, 0, 0);
 #endif
         if (stage) ws.piece(ws.k + 2 + G, t);     // one direct load per four MFMAs
 #ifndef XR_NO_VALU
@@ -128,7 +129,8 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
 #endif
     }
 }
-template <int KG, class VAL>
+// NG = 1: only accumulator group 0 (features 0 .. 127) is computed -- the stream, its barriers and the operand build are unchanged
+template <int KG, int NG = 2, class VAL>
 __device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) {
     static_assert(KG % 2 == 0, "k-step pairs");
     FragB b;
@@ -139,10 +141,10 @@ __device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) {
         float v[8];
         FragA a1;
         ws.read_group(a1, ws.k, 1);
-        mfma_group<0>(C, ws, ws.a0, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        mfma_group<0, true>(C, ws, ws.a0, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
         if (s & 1) ws.landed_barrier();
         ws.read_group(ws.a0, ws.k + 1, 0);
-        mfma_group<1>(C, ws, a1, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        mfma_group<1, NG == 2>(C, ws, a1, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
         b = nb;
         ++ws.k;
     }

@@ -46,6 +46,7 @@ class Engine:
         # NOT the default; also settable per renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
         self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
         self._x3 = None
+        self.x3_infer_min = 16384      # points: below this a launch of 64/128-point tiles does not fill the chip
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -314,7 +315,12 @@ class PointCtx:
 
 def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
     ctx = PointCtx(self, pts, flags, m_color)
-    check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), self.st()), "es_point_forward")
+    if self.split_precision and (flags & _lib.PF_DEFORM) and not (flags & _lib.PF_SAVE) and pts.M >= self.x3_infer_min:
+        # opt-in: the deformation-network launches of a large no-grad evaluation in split precision (csrc/infer_x3r.hip)
+        check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(self.packed_x3(weff, True)), ptr(weff), ptr(ctx.ws), flags, int(m_color),
+                                           self.st()), "es_point_forward_x3")
+    else:
+        check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), self.st()), "es_point_forward")
     return ctx
 
 
