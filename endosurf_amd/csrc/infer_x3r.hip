@@ -232,12 +232,207 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     }
 }
 
+
+// ---- SDF network: value pass + geometry features + reverse sweep ------------------------------------------------------------------
+// SDFNetwork (endosurf.py:773-786) on x_c: sdf, the 256 geometry features (colour evaluations only) and the analytic reverse sweep
+// g_c = d sdf / d x_c (get_sdf_grad_from_canonical_space, :603-619).  A wave owns 32 points.  The reverse sweep needs
+// softplus'(z_l) = sigmoid(100 z_l) of every layer: the pre-activations z_0 .. z_6 (the accumulators at the end of a layer) go to
+// HBM in k-step order and come back through a SIDE stream of the weight pipeline -- 2 direct loads of 1 KB per wave and k-step
+// into their own ring of four k-steps, same barriers; z_7 is still in registers when the sweep starts.  The stack lives in
+// WS_S_ACT: [tile][wave][layer][k-step][piece][lane] x 16 B.
+constexpr int XS_ENC_LD = 41;       // floats per point row of the encoding / its adjoint (39 used; odd: conflict-free)
+constexpr int XS_ZRING_BYTES = XR_RING * 4 * 2048;
+constexpr int XS_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XS_ZRING_BYTES + (128 * XS_ENC_LD + 9 * 256 + 256 + 4) * 4;
+static_assert(XS_LDS_BYTES <= 160 * 1024, "LDS carve");
+__device__ __forceinline__ float sigmoid100(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-144.26950408889634f * z)); }
+
+template <bool DEFORM, bool COLOR>
+__global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                             float* __restrict__ ws_xc, float* __restrict__ ws_sdf, float* __restrict__ ws_feat,
+                                                             float* __restrict__ ws_gc, float* __restrict__ ws_go, float4* __restrict__ zst, int Mp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
+    unsigned char* zring = ldsr + XR_RING * XR_CHUNK_BYTES;
+    float* encs = reinterpret_cast<float*>(zring + XS_ZRING_BYTES);                // [128 points][41]: enc6(x_c), later its adjoint
+    float* biasL = encs + 128 * XS_ENC_LD;                                         // [9][256]: layers 0..7, feature rows of layer 8
+    float* w8L = biasL + 9 * 256;                                                  // [256] row 0 of layer 8, then its bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int point = blockIdx.x * 128 + wave * 32 + n;
+    const bool live = point < Mp;
+    const bool wave_live = blockIdx.x * 128 + wave * 32 < Mp;                      // wave-uniform: the stack has no room for dead waves
+    float* erow = encs + (wave * 32 + n) * XS_ENC_LD;
+    float x[3];
+    if (DEFORM) {
+        const float* xc = ws_xc + (size_t)(live ? point : 0) * 3;
+        x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
+    } else {
+        float t, d[3];
+        load_point(src, point, x, t, d);
+        if (live && hi == 0) { ws_xc[(size_t)point * 3] = x[0]; ws_xc[(size_t)point * 3 + 1] = x[1]; ws_xc[(size_t)point * 3 + 2] = x[2]; }
+    }
+    for (int i = tid; i < 9 * 256; i += XR_THREADS) {
+        const int l = i >> 8, f = i & 255;
+        biasL[i] = l < 8 ? weff[tb.boff[NET_S * LAYERS + l] + f] : weff[tb.boff[NET_S * LAYERS + 8] + 1 + f];
+    }
+    for (int i = tid; i < 256; i += XR_THREADS) w8L[i] = weff[tb.woff[NET_S * LAYERS + 8] + i];
+    if (tid == 0) w8L[256] = weff[tb.boff[NET_S * LAYERS + 8]];
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii) {
+        const int i = 3 * hi + ii;
+        const float f = (float)(1 << i);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincosf(x[c] * f, &s, &co);
+            erow[enc_index(3, i, 0, c)] = s;
+            erow[enc_index(3, i, 1, c)] = co;
+        }
+    }
+    if (hi == 0) { erow[0] = x[0]; erow[1] = x[1]; erow[2] = x[2]; }
+    __syncthreads();
+    // logical k-steps: [0, 120) SF0 .. SF7, then (colour: SF8F,) SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0
+    constexpr int KR0 = XR_SDF_FWD_CHUNKS + (COLOR ? 16 : 0);                       // first k-step of the reverse sweep
+    WStream ws;
+    ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane;
+    ws.e0 = XR_SDF_FWD_CHUNKS; ws.b0 = XR_SDF_CHUNK0; ws.b1 = XR_SI_CHUNK0 + (COLOR ? 0 : 16);
+    ws.start();
+
+    float4* zmine = zst + ((size_t)(blockIdx.x * 4 + wave) * 8 * 16 * 2) * 64 + lane;      // + ((layer * 16 + s) * 2 + piece) * 64
+    // the side stream: pre-activations of the layer whose softplus' the reverse GEMM of k-step kk needs
+    const auto side = [&](int kk, int t) {
+        if (t != 1 && t != 4) return;
+        const int r = kk - (KR0 + 16);                       // SR7 reads z_7 from registers
+        if (r < 0 || r >= 8 * 16 || !wave_live) return;
+        const int gi = r >> 4, s = r & 15, layer = gi <= 2 ? 6 - gi : 7 - gi, piece = t == 4;     // SR6 SR5 SR4A SR4M SR3 SR2 SR1 SR0
+        const float4* srcp = zmine + ((layer * 16 + s) * 2 + piece) * 64;
+        unsigned char* dst = zring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    const auto enc_val = [&](int s, int j) -> float {
+        const int k = 16 * s + xr_kperm(hi, j);
+        return k < 39 ? erow[k] : 0.f;
+    };
+    f32x16 P[8], C[8];
+    init8(C, biasL, hi);
+    gemm_r<4>(C, ws, enc_val, side);
+    const auto act_val = [&](int s, int j) -> float {
+        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
+        return softplus100_native(P[b][4 * q + i]);
+    };
+    const auto push_z = [&](int layer) {                     // z_layer = C, in the k-step order of the operand it becomes
+        if (!wave_live) return;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int r0 = 8 * (s & 1) + 4 * pc;
+                zmine[((layer * 16 + s) * 2 + pc) * 64] = make_float4(C[s >> 1][r0], C[s >> 1][r0 + 1], C[s >> 1][r0 + 2], C[s >> 1][r0 + 3]);
+            }
+    };
+    push_z(0);
+    copy8(P, C);
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        init8(C, biasL + l * 256, hi);
+        gemm_r<16>(C, ws, act_val, side);
+        if (l == 4) gemm_r<4>(C, ws, enc_val, side);           // NeRF skip: + encoding part (SF4A follows SF4M)
+        if (l < 7) push_z(l);
+        copy8(P, C);
+    }
+    // P = z_7
+    if (COLOR) {       // geometry features = rows 1 .. 256 of the last layer
+        init8(C, biasL + 8 * 256, hi);
+        gemm_r<16>(C, ws, act_val, side);
+        if (live) {
+            float* fo = ws_feat + (size_t)point * 256;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(fo + 32 * b + 8 * q + 4 * hi) = make_float4(C[b][4 * q], C[b][4 * q + 1], C[b][4 * q + 2], C[b][4 * q + 3]);
+        }
+    }
+    {
+        float s0 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0 = fmaf(w8L[32 * b + 8 * (r >> 2) + 4 * hi + (r & 3)], softplus100_native(P[b][r]), s0);
+        s0 += __shfl_xor(s0, 32);
+        if (hi == 0 && live) ws_sdf[point] = s0 + w8L[256];
+    }
+    // ---- reverse sweep: rho_l = softplus'(z_l) . (adjoint of s_{l+1}),  adjoint of s_l = W_l^T rho_l ----
+    const auto zero = [&](f32x16(&A)[8], int nb) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b < nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) A[b][r] = 0.f;
+    };
+    zero(C, 8);
+    gemm_r<16>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
+        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
+        return sigmoid100(P[b][4 * q + i]) * w8L[32 * b + 8 * q + 4 * hi + i];
+    }, side);
+    copy8(P, C);
+    int kb = 0;                                                  // first k-step of the running GEMM (its z slots)
+    const auto rho_val = [&](int s, int j) -> float {
+        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
+        const float z = reinterpret_cast<const float*>(zring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
+        return sigmoid100(z) * P[b][4 * q + i];
+    };
+    f32x16 E[8];                                                 // adjoint of the encoding input (blocks 0, 1): skip part + layer 0
+    zero(E, 4);
+#pragma unroll 1
+    for (int l = 6; l >= 1; --l) {
+        if (l == 4) {                                            // encoding part of the skip layer's input adjoint, same operand rho_4
+            kb = ws.k;
+            gemm_r<16, 1, true>(E, ws, rho_val, side);
+        }
+        kb = ws.k;
+        zero(C, 8);
+        gemm_r<16, 2, true>(C, ws, rho_val, side);
+        copy8(P, C);
+    }
+    kb = ws.k;
+    gemm_r<16, 1, true>(E, ws, rho_val, side);                   // += W_0^T rho_0
+    // g_c[j] = sum_k adj[k] * d enc_k / d x_j
+    __syncthreads();                                             // everybody is done with the encoding rows
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (f < 39) erow[f] = E[b][r];
+        }
+    if (hi == 0 && live) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float gv = erow[j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float f = (float)(1 << i);
+                float s, co;
+                sincosf(x[j] * f, &s, &co);
+                gv += f * (erow[enc_index(3, i, 0, j)] * co - erow[enc_index(3, i, 1, j)] * s);
+            }
+            ws_gc[(size_t)point * 3 + j] = gv;
+            if (!DEFORM) ws_go[(size_t)point * 3 + j] = gv;      // with a deformation network g_o = J^T g_c is the VJP sweep
+        }
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 static int infer_attrs() {
     static DeviceOnce attr_done;
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_deform_jvp_x3r, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false>, XS_LDS_BYTES)) return e;
         attr_done.done();
     }
     return ST_OK;
@@ -258,6 +453,22 @@ int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
     hipLaunchKernelGGL(k_deform_vjp_x3r, dim3((L.Mp + 127) / 128), dim3(XR_THREADS), XI_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
                        ws + L.off[WS_GC], ws + L.off[WS_GO], reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]), L.Mp);
     return hip_last("deform_vjp_x3r");
+}
+
+// all Mp points get sdf / g_c (/ g_o); the geometry features (m_feat > 0) are written for every point as well
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st) {
+    if (int e = infer_attrs()) return e;
+    const Tabs tb = make_tabs();
+    ScopedTimer tm(KID_SDF_FWD, src.M, st);
+    const dim3 grid((L.Mp + 127) / 128), block(XR_THREADS);
+    const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
+    float* xc = ws + L.off[WS_XC]; float* sdf = ws + L.off[WS_SDF]; float* feat = ws + L.off[WS_FEAT]; float* gc = ws + L.off[WS_GC];
+    float* go = ws + L.off[WS_GO]; float4* zst = reinterpret_cast<float4*>(ws + L.off[WS_S_ACT]);
+#define ES_LAUNCH_SDF_X3R(D, Cc) hipLaunchKernelGGL((k_sdf_fwd_x3r<D, Cc>), grid, block, XS_LDS_BYTES, st, src, tb, pk, weff, xc, sdf, feat, gc, go, zst, L.Mp)
+    if (deform) { if (color) ES_LAUNCH_SDF_X3R(true, true); else ES_LAUNCH_SDF_X3R(true, false); }
+    else { if (color) ES_LAUNCH_SDF_X3R(false, true); else ES_LAUNCH_SDF_X3R(false, false); }
+#undef ES_LAUNCH_SDF_X3R
+    return hip_last("sdf_fwd_x3r");
 }
 
 }  // namespace es

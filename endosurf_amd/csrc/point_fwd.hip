@@ -545,10 +545,11 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 // infer_x3r.hip / query_x3.hip
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
 int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
-// packed_x3 (nullable): the split weights of es_pack_x3; with PF_X3 and without PF_SAVE the deformation-network launches of a no-grad
-// evaluation run in split precision (opt-in)
+// packed_x3 (nullable): the split weights of es_pack_x3; with PF_X3 and without PF_SAVE the deformation- and SDF-network launches of a
+// no-grad evaluation run in split precision (opt-in)
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st,
                   const void* packed_x3) {
     if (src.M <= 0) return ST_OK;
@@ -558,12 +559,13 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
-    if (deform && (flags & PF_X3) && !(flags & PF_SAVE) && packed_x3) {
+    if ((flags & PF_X3) && !(flags & PF_SAVE) && packed_x3) {
+        // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour (fp32) | VJP
         const void* pr = packed_x3r_part(packed_x3);
-        if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, st)) return e;
-        { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, st)) return e; }
+        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, st)) return e;
         if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
-        return deform_vjp_x3r(src, pr, weff, ws, a.L, st);
+        return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, st) : hip_last("point_forward");
     }
     if (deform && aux_tail(flags, a.M_color, src.M)) {
         // main tiles [0, Mc), colour-less tail [Mc, Mp).  Every main launch is a whole number of rounds of the 512 workgroup

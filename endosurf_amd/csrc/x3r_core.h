@@ -7,9 +7,11 @@
 namespace es {
 
 // segments in the order the kernels walk them: [0, 8) deformation forward, [8, 17) SDF forward (query_x3r.hip, infer_x3r.hip value
-// passes), [17, 25) deformation reverse DR7 .. DR0 (the VJP sweep of infer_x3r.hip)
+// passes), [17, 25) deformation reverse DR7 .. DR0 (the VJP sweep of infer_x3r.hip), [25, 35) the geometry-feature layer and the SDF
+// reverse sweep (the encoding part of the skip layer's adjoint before its hidden part: both read the same operand)
 constexpr int XR_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7,
-                           DR7, DR6, DR5, DR4, DR3, DR2, DR1, DR0};
+                           DR7, DR6, DR5, DR4, DR3, DR2, DR1, DR0,
+                           SF8F, SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0};
 constexpr int XR_COUNT = sizeof(XR_SEGS) / sizeof(int);
 constexpr int xr_kg(int i) { return 2 * cdiv(SEGS[XR_SEGS[i]].kreal, 32); }      // k-steps, even (the stream works in pairs)
 constexpr int xr_chunk0(int i) {
@@ -22,12 +24,14 @@ constexpr int XR_PAD_CHUNKS = 4;                          // a stream reads up t
 constexpr int XR_SDF_CHUNK0 = xr_chunk0(8);               // first k-step of SF0
 constexpr int XR_QUERY_CHUNKS = xr_chunk0(17);            // 236: end of the query stream
 constexpr int XR_DR_CHUNK0 = xr_chunk0(17);               // first k-step of DR7
+constexpr int XR_SI_CHUNK0 = xr_chunk0(25);               // first k-step of SF8F (then SR7 ...)
+constexpr int XR_SDF_FWD_CHUNKS = XR_QUERY_CHUNKS - XR_SDF_CHUNK0;      // 120 k-steps of SF0 .. SF7
 constexpr int XR_CHUNK_UNITS = 8 * 3;                     // 1 KB units (64 lanes x 16 B) per k-step
 constexpr int XR_CHUNK_BYTES = XR_CHUNK_UNITS * 1024;
 constexpr int XR_THREADS = 256;
 constexpr int XR_ENC_LD = 68;                             // floats per column row of the encoding scratch (conflict-free b32 / b128 reads)
 constexpr int XR_RING = 4;                                // k-steps resident in LDS
-static_assert(XR_SDF_CHUNK0 % 2 == 0 && XR_DR_CHUNK0 % 2 == 0 && XR_CHUNKS % 2 == 0, "k-step pairs");
+static_assert(XR_SDF_CHUNK0 % 2 == 0 && XR_DR_CHUNK0 % 2 == 0 && XR_SI_CHUNK0 % 2 == 0 && XR_CHUNKS % 2 == 0, "k-step pairs");
 static_assert(LAYER_N[NET_D][3] == 204 && LAYER_N[NET_S][7] == 256 && SEGS[SF4A].kreal == 39, "shapes the kernels hard-code");
 
 // position j (0..7) of lane half hi in k-step-local order -> k offset inside the 16-wide step
@@ -44,13 +48,17 @@ __host__ __device__ constexpr int xr_kperm(int hi, int j) { return j < 4 ? 4 * h
 // after a barrier are requested before the MFMAs that follow it.  A bare s_barrier + explicit vmcnt: nothing else is in flight.
 struct FragA { u32x4 p[4][3]; };
 struct WStream {
-    const u32x4* g;          // k-step 0
+    const u32x4* g;          // k-step 0 of the packed buffer
     unsigned char* ring;
-    int k, wave, lane;       // k = the k-step being computed
+    int k, wave, lane;       // k = the (logical) k-step being computed
+    // logical -> packed k-step: a kernel walks up to three ranges of the packed order back to back: [.., e0) -> b0 + k,
+    // [e0, e1) -> b1 + (k - e0), [e1, ..) -> b2 + (k - e1)
+    int e0 = 0x7fffffff, e1 = 0x7fffffff, b0 = 0, b1 = 0, b2 = 0;
     FragA a0;                // fragments of (k, group 0), read ahead
+    __device__ __forceinline__ int packed_step(int kk) const { return kk < e0 ? b0 + kk : (kk < e1 ? b1 + (kk - e0) : b2 + (kk - e1)); }
     __device__ __forceinline__ void piece(int kk, int i) {
 #ifndef XR_NO_DMA
-        const u32x4* src = g + ((size_t)kk * XR_CHUNK_UNITS + wave * 6 + i) * 64 + lane;
+        const u32x4* src = g + ((size_t)packed_step(kk) * XR_CHUNK_UNITS + wave * 6 + i) * 64 + lane;
         unsigned char* dst = ring + (kk & (XR_RING - 1)) * XR_CHUNK_BYTES + (wave * 6 + i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 #endif
@@ -100,9 +108,10 @@ __device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s) {
 // between the MFMAs of k-step s.  MFMA order: term-major over groups of 4 accumulators -- consecutive MFMAs never share an
 // accumulator (an instruction issued between two MFMAs of one accumulate chain costs ~40 cycles, between independent ones ~6), the
 // six partial products of an accumulator still arrive smallest first.  KG is even and ws.k is even on entry.
-template <int G, bool MFMA, class VAL>
+struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+template <int G, bool MFMA, class VAL, class SIDE>
 __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const FragA& a, const FragB& b, FragB& nb, float (&v)[8], VAL&& val, int snext,
-                                           bool more, bool stage) {
+                                           bool more, bool stage, bool late, SIDE&& side) {
     // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
     constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -115,23 +124,33 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
                 C[4 * G + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[f][TA[t]]), __builtin_bit_cast(bf16x8, bt),
                                                                       C[4 * G + f], 0, 0, 0);
 #endif
-        if (stage) ws.piece(ws.k + 2 + G, t);     // one direct load per four MFMAs
+        if (stage) {
+            ws.piece(ws.k + 2 + G, t);     // one direct load per four MFMAs
+            side(ws.k + 2 + G, t);         // a kernel's own per-k-step operand stream (same slots, same barriers)
+        }
 #ifndef XR_NO_VALU
-        const int k = 4 * G + t;                  // 8 of the 12 (group, term) slots build one value each
         if (more && t < 4) {
-            v[k] = val(snext, k);
-            if (k & 1) {
-                unsigned hh, mm, ll;
-                split_pair(v[k - 1], v[k], hh, mm, ll);
-                nb.h[k >> 1] = hh; nb.m[k >> 1] = mm; nb.l[k >> 1] = ll;
+            // 8 of the 12 (group, term) slots build one value each; late (values that depend on data landing at this k-step's barrier):
+            // all 8 in group 1, two per slot
+            const int k0 = late ? 2 * t : 4 * G + t, nk = late ? (G == 1 ? 2 : 0) : 1;
+#pragma unroll
+            for (int k = k0; k < k0 + nk; ++k) {
+                v[k] = val(snext, k);
+                if (k & 1) {
+                    unsigned hh, mm, ll;
+                    split_pair(v[k - 1], v[k], hh, mm, ll);
+                    nb.h[k >> 1] = hh; nb.m[k >> 1] = mm; nb.l[k >> 1] = ll;
+                }
             }
         }
 #endif
     }
 }
-// NG = 1: only accumulator group 0 (features 0 .. 127) is computed -- the stream, its barriers and the operand build are unchanged
-template <int KG, int NG = 2, class VAL>
-__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) {
+// NG = 1: only accumulator group 0 (features 0 .. 127) is computed -- the stream, its barriers and the operand build are unchanged.
+// LATE: val(s, .) of an EVEN k-step s reads data that lands with the barrier inside k-step s - 1 (a side stream): those operands are
+// built after that barrier.
+template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE>
+__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side) {
     static_assert(KG % 2 == 0, "k-step pairs");
     FragB b;
     build_frag(b, val, 0);
@@ -141,14 +160,16 @@ __device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) {
         float v[8];
         FragA a1;
         ws.read_group(a1, ws.k, 1);
-        mfma_group<0, true>(C, ws, ws.a0, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        mfma_group<0, true>(C, ws, ws.a0, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0, LATE && (s & 1), side);
         if (s & 1) ws.landed_barrier();
         ws.read_group(ws.a0, ws.k + 1, 0);
-        mfma_group<1, NG == 2>(C, ws, a1, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0);
+        mfma_group<1, NG == 2>(C, ws, a1, b, nb, v, val, s + 1, s + 1 < KG, (s & 1) == 0, LATE && (s & 1), side);
         b = nb;
         ++ws.k;
     }
 }
+template <int KG, int NG = 2, class VAL>
+__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) { gemm_r<KG, NG, false>(C, ws, val, NoSide()); }
 
 // accumulators start from the layer's bias: register 4 q + i of block b is feature 32 b + 8 q + 4 hi + i
 __device__ __forceinline__ void init8(f32x16 (&C)[8], const float* bl, int hi) {

@@ -315,9 +315,10 @@ class PointCtx:
 
 def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
     ctx = PointCtx(self, pts, flags, m_color)
-    if self.split_precision and (flags & _lib.PF_DEFORM) and not (flags & _lib.PF_SAVE) and pts.M >= self.x3_infer_min:
-        # opt-in: the deformation-network launches of a large no-grad evaluation in split precision (csrc/infer_x3r.hip)
-        check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(self.packed_x3(weff, True)), ptr(weff), ptr(ctx.ws), flags, int(m_color),
+    if self.split_precision and not (flags & _lib.PF_SAVE) and pts.M >= self.x3_infer_min:
+        # opt-in: the deformation- and SDF-network launches of a large no-grad evaluation in split precision (csrc/infer_x3r.hip)
+        px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
+        check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(px3), ptr(weff), ptr(ctx.ws), flags, int(m_color),
                                            self.st()), "es_point_forward_x3")
     else:
         check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), self.st()), "es_point_forward")
