@@ -1,6 +1,6 @@
-// Opt-in split-precision INFERENCE kernels of the deformation network on the register-resident GEMM core (x3r_core.h; formulation and
-// arithmetic in query_x3r.hip / query_x3.hip).  They replace the fp32 deform_fwd / deform_vjp launches of point_fwd.hip when a no-grad
-// point evaluation is requested with PF_X3 (no PF_SAVE):
+// Opt-in split-precision INFERENCE chain on the register-resident GEMM core (x3r_core.h; formulation and arithmetic in query_x3r.hip /
+// query_x3.hip).  The kernels replace the fp32 launches of point_fwd.hip when a no-grad point evaluation is requested with PF_X3 (no
+// PF_SAVE); they read and write the same workspace buffers (k_sdf_fwd_x3r and k_color_fwd_x3r are described where they are defined):
 //   k_deform_jvp_x3r   DeformNetwork (reference endosurf.py:724-738) value + forward-mode tangent along the ray direction:
 //                      x_c = x + MLP(x, t) and v = J d.  A wave owns 16 points = 32 columns: lanes 0-15 of a lane half hold the value
 //                      column of a point, lanes 16-31 its tangent column; the ReLU mask of a tangent element is the sign of the value
@@ -423,6 +423,119 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     }
 }
 
+
+// ---- colour network -----------------------------------------------------------------------------------------------------------------
+// ColorNetwork (endosurf.py:828-842) on [enc10(x_c) 63 | g_c 3 | enc4(d_c) 27 | feat 256] -> sigmoid rgb; d_c = J d / (|J d| + 1e-10)
+// (:684-685).  A wave owns 32 points.  The 93-wide small part of the input is evaluated where it is consumed (layer 0 and the skip
+// layer): every lane computes exactly the 8 operand elements of its half of a k-step.  The geometry features come back from the
+// row-major WS_FEAT as a side stream of the weight pipeline (direct loads with per-lane source addresses: 2 x 16 B per lane and k-step).
+constexpr int XC_FRING_BYTES = XR_RING * 4 * 2048;
+constexpr int XC_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XC_FRING_BYTES + (8 * 256 + 3 * 256 + 4) * 4;
+constexpr int XC_K_0S = 0, XC_K_0F = 6, XC_K_4S = 6 + 16 + 48 + 16, XC_K_4F = XC_K_4S + 6;     // logical k-steps of CF0S, CF0F, CF4S, CF4F
+static_assert(xr_kg(35) == 6 && xr_kg(41) == 6 && XC_K_4F == 92, "colour stream layout");
+
+template <bool DEFORM>
+__global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                               const float* __restrict__ ws_xc, const float* __restrict__ ws_v,
+                                                               const float* __restrict__ ws_gc, const float* __restrict__ ws_feat,
+                                                               float* __restrict__ ws_rgb, int Mcp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
+    unsigned char* fring = ldsr + XR_RING * XR_CHUNK_BYTES;
+    float* biasL = reinterpret_cast<float*>(fring + XC_FRING_BYTES);               // [8][256]
+    float* w8L = biasL + 8 * 256;                                                  // [3][256] last-layer rows, then its 3 biases
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int point = blockIdx.x * 128 + wave * 32 + n;
+    const bool live = point < Mcp;
+    const size_t pl = live ? point : 0;
+    float xc[3], gc[3], dc[3];
+    {
+        float x[3], t, d[3];
+        load_point(src, (int)pl, x, t, d);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xc[c] = ws_xc[pl * 3 + c]; gc[c] = ws_gc[pl * 3 + c]; dc[c] = DEFORM ? ws_v[pl * 3 + c] : d[c]; }
+        const float inv = 1.f / (sqrtf(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]) + 1e-10f);
+        dc[0] *= inv; dc[1] *= inv; dc[2] *= inv;
+    }
+    for (int i = tid; i < 8 * 256; i += XR_THREADS) biasL[i] = weff[tb.boff[NET_C * LAYERS + (i >> 8)] + (i & 255)];
+    for (int i = tid; i < 3 * 256; i += XR_THREADS) w8L[i] = weff[tb.woff[NET_C * LAYERS + 8] + i];
+    if (tid < 3) w8L[3 * 256 + tid] = weff[tb.boff[NET_C * LAYERS + 8] + tid];
+    __syncthreads();
+    WStream ws;
+    ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane; ws.b0 = XR_C_CHUNK0;
+    ws.start();
+
+    const float* frow = ws_feat + pl * 256;
+    const auto side = [&](int kk, int t) {                    // geometry features of k-step s of CF0F / CF4F
+        if (t != 1 && t != 4) return;
+        int s = kk - XC_K_0F;
+        if (s < 0 || s >= 16) s = kk - XC_K_4F;
+        if (s < 0 || s >= 16) return;
+        const int piece = t == 4;
+        const float* srcp = frow + 16 * s + 4 * hi + 8 * piece;      // features 32 b + 16 p + 4 hi (+ 8): the k order of the operand
+        unsigned char* dst = fring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    int kb = 0;
+    const auto feat_val = [&](int s, int j) -> float {
+        return reinterpret_cast<const float*>(fring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + (j & 3)];
+    };
+    // element k of [enc10(x_c) 63 | g_c 3 | enc4(d_c) 27 | 0 0 0]
+    const auto small_val = [&](int s, int j) -> float {
+        int k = 16 * s + xr_kperm(hi, j);
+        if (k >= 93) return 0.f;
+        if (k >= 63 && k < 66) return k == 63 ? gc[0] : (k == 64 ? gc[1] : gc[2]);
+        const bool dir = k >= 66;
+        if (dir) k -= 66;
+        const float p0 = dir ? dc[0] : xc[0], p1 = dir ? dc[1] : xc[1], p2 = dir ? dc[2] : xc[2];
+        if (k < 3) return k == 0 ? p0 : (k == 1 ? p1 : p2);
+        const int i = (k - 3) / 6, rem = (k - 3) - 6 * i, fn = rem >= 3, c = rem - 3 * fn;
+        float sn, co;
+        sincosf((c == 0 ? p0 : (c == 1 ? p1 : p2)) * (float)(1 << i), &sn, &co);
+        return fn ? co : sn;
+    };
+    f32x16 P[8], C[8];
+    const auto relu_val = [&](int s, int j) -> float {
+        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
+        return fmaxf(P[b][4 * q + i], 0.f);
+    };
+    init8(C, biasL, hi);
+    gemm_r<6>(C, ws, small_val, side);
+    kb = ws.k;
+    gemm_r<16, 2, true>(C, ws, feat_val, side);
+    copy8(P, C);
+#pragma unroll 1
+    for (int l = 1; l <= 7; ++l) {
+        init8(C, biasL + l * 256, hi);
+        gemm_r<16>(C, ws, relu_val, side);
+        if (l == 4) {       // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
+            gemm_r<6>(C, ws, small_val, side);
+            kb = ws.k;
+            gemm_r<16, 2, true>(C, ws, feat_val, side);
+        }
+        copy8(P, C);
+    }
+    {
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
+                const float h = fmaxf(P[b][r], 0.f);
+                d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
+            }
+        d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+        if (hi == 0 && live) {
+            float* o = ws_rgb + (size_t)point * 3;
+            o[0] = 1.f / (1.f + expf(-(d0 + w8L[768])));
+            o[1] = 1.f / (1.f + expf(-(d1 + w8L[769])));
+            o[2] = 1.f / (1.f + expf(-(d2 + w8L[770])));
+        }
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 static int infer_attrs() {
     static DeviceOnce attr_done;
@@ -433,6 +546,8 @@ static int infer_attrs() {
         if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<true>, XC_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<false>, XC_LDS_BYTES)) return e;
         attr_done.done();
     }
     return ST_OK;
@@ -469,6 +584,21 @@ int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, fl
     else { if (color) ES_LAUNCH_SDF_X3R(false, true); else ES_LAUNCH_SDF_X3R(false, false); }
 #undef ES_LAUNCH_SDF_X3R
     return hip_last("sdf_fwd_x3r");
+}
+
+// colour of the points [0, Mcp)
+int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, hipStream_t st) {
+    if (int e = infer_attrs()) return e;
+    if (Mcp <= 0) return ST_OK;
+    const Tabs tb = make_tabs();
+    ScopedTimer tm(KID_COLOR_FWD, Mcp, st);
+    const dim3 grid((Mcp + 127) / 128), block(XR_THREADS);
+    const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
+    if (deform) hipLaunchKernelGGL(k_color_fwd_x3r<true>, grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], ws + L.off[WS_GC],
+                                   ws + L.off[WS_FEAT], ws + L.off[WS_RGB], Mcp);
+    else hipLaunchKernelGGL(k_color_fwd_x3r<false>, grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], ws + L.off[WS_GC],
+                            ws + L.off[WS_FEAT], ws + L.off[WS_RGB], Mcp);
+    return hip_last("color_fwd_x3r");
 }
 
 }  // namespace es

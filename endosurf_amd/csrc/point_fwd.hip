@@ -546,6 +546,7 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
 int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
 int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st);
+int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
 // packed_x3 (nullable): the split weights of es_pack_x3; with PF_X3 and without PF_SAVE the deformation- and SDF-network launches of a
@@ -560,11 +561,11 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
     if ((flags & PF_X3) && !(flags & PF_SAVE) && packed_x3) {
-        // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour (fp32) | VJP
+        // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour | VJP
         const void* pr = packed_x3r_part(packed_x3);
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, st)) return e; }
         if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, st)) return e;
-        if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
+        if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, st) : hip_last("point_forward");
     }
     if (deform && aux_tail(flags, a.M_color, src.M)) {
