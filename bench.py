@@ -77,7 +77,8 @@ def kernel_macs(name, use_deform):
     return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_query_sdf_x3": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
             "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D,
             "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C,
-            "k_wgrad_x3[deform]": 3 * MAC_D, "k_wgrad_x3[sdf]": 2 * MAC_S, "k_wgrad_x3[color]": MAC_C}.get(name)
+            "k_wgrad_x3[deform]": 3 * MAC_D, "k_wgrad_x3[sdf]": 2 * MAC_S, "k_wgrad_x3[color]": MAC_C,
+            "k_deform_fwd_x3": 2 * MAC_D, "k_deform_vjp_x3": MAC_D, "k_sdf_fwd_x3": 2 * MAC_S, "k_color_fwd_x3": MAC_C}.get(name)
 
 
 def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
@@ -334,7 +335,8 @@ def main():
                         fp32_equivalent_tflops=d["tflops"], share_of_timed_kernel_time=d["share_of_timed_kernel_time"],
                         end_to_end=dict(achieved=e2e, frac=e2e / PEAK_F32_MFMA, unit="TFLOP/s", flops_per_step=flops_per_step,
                                         note="executed fp32-equivalent GEMM FLOPs of one step (2 x MACs x points of every timed launch) / "
-                                             "ms_per_step, against the fp32 MFMA peak"),
+                                             "ms_per_step, against the fp32 MFMA peak (a split-precision run can exceed it: its GEMMs run on "
+                                             "the bf16 pipes)"),
                         peak_note=("bf16 MFMA dense peak (v_mfma_f32_32x32x16_bf16); achieved = 6 bf16 partial products per fp32-equivalent MAC"
                                    if x3 else "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"))
         what = {"train": "full train step: render + errorondepth + surface_neighbour_error + loss + backward + Adam",
@@ -344,8 +346,9 @@ def main():
                            "frame": "full-frame render rays/sec (640x512, %d samples, %d-ray chunks)" % (S, args.chunk)}[mode],
                    value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                    scaling="strong" if mode == "frame" else "weak", vs_baseline=None,
-                   dtype="f32" if not args.split_precision else "f32 (OPT-IN split precision: large SDF queries and weight-gradient GEMMs as 3 x bf16 "
-                                                                "planes, 6 partial products, fp32 accumulate; not the headline configuration)",
+                   dtype="f32" if not args.split_precision else "f32 (OPT-IN split precision: large SDF queries, the no-grad point-evaluation chain and the "
+                                                                "weight-gradient GEMMs as 3 x bf16 planes, 6 partial products, fp32 accumulate; not the "
+                                                                "headline configuration)",
                    data="synthetic",
                    config=dict(workload="BASELINE config %d: %s nets, %d rays x (%d+%d) samples per GPU, %s" % (
                        args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),

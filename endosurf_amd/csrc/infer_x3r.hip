@@ -556,7 +556,7 @@ static int infer_attrs() {
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_DEFORM_FWD, src.M, st);
+    ScopedTimer tm(KID_DEFORM_FWD_X3, src.M, st);
     hipLaunchKernelGGL(k_deform_jvp_x3r, dim3(L.Mp / 64), dim3(XR_THREADS), XI_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
                        ws + L.off[WS_XC], ws + L.off[WS_V], reinterpret_cast<u32x4*>(ws + L.off[WS_D_MASK]), L.Mp);
     return hip_last("deform_jvp_x3r");
@@ -564,7 +564,7 @@ int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
 int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_DEFORM_VJP, src.M, st);
+    ScopedTimer tm(KID_DEFORM_VJP_X3, src.M, st);
     hipLaunchKernelGGL(k_deform_vjp_x3r, dim3((L.Mp + 127) / 128), dim3(XR_THREADS), XI_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
                        ws + L.off[WS_GC], ws + L.off[WS_GO], reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]), L.Mp);
     return hip_last("deform_vjp_x3r");
@@ -574,7 +574,7 @@ int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
 int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_SDF_FWD, src.M, st);
+    ScopedTimer tm(KID_SDF_FWD_X3, src.M, st);
     const dim3 grid((L.Mp + 127) / 128), block(XR_THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
     float* xc = ws + L.off[WS_XC]; float* sdf = ws + L.off[WS_SDF]; float* feat = ws + L.off[WS_FEAT]; float* gc = ws + L.off[WS_GC];
@@ -591,7 +591,7 @@ int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, 
     if (int e = infer_attrs()) return e;
     if (Mcp <= 0) return ST_OK;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_COLOR_FWD, Mcp, st);
+    ScopedTimer tm(KID_COLOR_FWD_X3, Mcp, st);
     const dim3 grid((Mcp + 127) / 128), block(XR_THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
     if (deform) hipLaunchKernelGGL(k_color_fwd_x3r<true>, grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], ws + L.off[WS_GC],
