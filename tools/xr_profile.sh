@@ -5,7 +5,7 @@ L=endosurf_amd/lib; B=endosurf_amd/build; S=endosurf_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
 if [ "$1" != run ]; then
   python -m endosurf_amd.build >/dev/null || exit 1
-  for v in "prof1:-DXR_PROFILE=1" "prof2:-DXR_PROFILE=2" "novalu:-DXR_PROFILE=1 -DXR_NO_VALU" "nodma:-DXR_PROFILE=1 -DXR_NO_DMA" "nobar:-DXR_PROFILE=1 -DXR_NO_BARRIER" "nodmabar:-DXR_PROFILE=1 -DXR_NO_DMA -DXR_NO_BARRIER" "nothing:-DXR_PROFILE=1 -DXR_NO_DMA -DXR_NO_BARRIER -DXR_NO_VALU"; do
+  for v in "prof1:-DXR_PROFILE=1" "prof2:-DXR_PROFILE=2" "nopin:-DXR_PROFILE=1 -DXR_NO_PIN" "novalu:-DXR_PROFILE=1 -DXR_NO_VALU" "nodma:-DXR_PROFILE=1 -DXR_NO_DMA" "nobar:-DXR_PROFILE=1 -DXR_NO_BARRIER" "nodmabar:-DXR_PROFILE=1 -DXR_NO_DMA -DXR_NO_BARRIER" "nothing:-DXR_PROFILE=1 -DXR_NO_DMA -DXR_NO_BARRIER -DXR_NO_VALU"; do
     name=${v%%:*}; defs=${v#*:}
     /opt/rocm/bin/hipcc $FLAGS $defs -c $S/query_x3r.hip -o /tmp/xr_$name.o || exit 1
     objs=$(ls $B/*.o | grep -v query_x3r.o)
