@@ -24,6 +24,12 @@ static_assert(XI_LDS_BYTES <= 160 * 1024, "LDS carve");
 __device__ __forceinline__ void mask_set(u32x4& mk, int b, int r, bool m) { mk[b >> 1] |= (m ? 1u : 0u) << ((b & 1) * 16 + r); }
 __device__ __forceinline__ bool mask_get(const u32x4& mk, int b, int r) { return (mk[b >> 1] >> ((b & 1) * 16 + r)) & 1u; }
 
+// the element of the VALUE column of this lane's point: lanes 0-15 of a lane half keep their own, lanes 16-31 get their partner's
+// (v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first operand with the even rows of its second)
+__device__ __forceinline__ float value_row(float z) {
+    return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false)[0]);
+}
+
 // ---- value + tangent ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                                 float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks, int Mp) {
@@ -100,8 +106,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float z = P[b][4 * q + i];
-            const float zo = __shfl_xor(z, 16);              // the partner column's element
-            const bool m = (tan ? zo : z) > 0.f;             // ReLU mask of the VALUE column gates both
+            const bool m = value_row(z) > 0.f;               // ReLU mask of the VALUE column gates both
             mask_set(mk, b, 4 * q + i, m);
             const float h = m ? z : 0.f;
             if (32 * b + 8 * q + 4 + i < 204) return h;
@@ -119,8 +124,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
             for (int r = 0; r < 16; ++r) {
                 const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
                 const float z = P[b][r];
-                const float zo = __shfl_xor(z, 16);
-                const bool m = (tan ? zo : z) > 0.f;
+                const bool m = value_row(z) > 0.f;
                 mask_set(mk, b, r, m);
                 const float h = m ? z : 0.f;
                 d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
