@@ -129,10 +129,13 @@ def pmc_traffic(symbol):
     """HBM bytes per launch of a kernel symbol from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
     FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/pmc_summary.py), launch-weighted over its launch sizes; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")), key=os.path.getmtime)
-    if not files:
-        return None
-    rows = [r for r in json.load(open(files[-1])) if r.get("logical", r["kernel"].split("<")[0]) == symbol and r.get("hbm_bytes") == r.get("hbm_bytes")]
+    # newest summary that has the symbol (by name: the round tags sort; mtimes are meaningless on a fresh copy of the tree)
+    rows, used = [], None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")), reverse=True):
+        rows = [r for r in json.load(open(f)) if r.get("logical", r["kernel"].split("<")[0]) == symbol and r.get("hbm_bytes") == r.get("hbm_bytes")]
+        if rows:
+            used = f
+            break
     if not rows:
         return None
     # one timed launch may be two kernels (the halves of the deformation launch, point_fwd.hip): bytes per logical launch =
@@ -141,7 +144,7 @@ def pmc_traffic(symbol):
     by_kernel = {}
     for r in rows:
         by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0) + r["launches"]
-    return total / max(by_kernel.values()), os.path.basename(files[-1])
+    return total / max(by_kernel.values()), os.path.basename(used)
 
 
 def kernel_timing(eng, step, first_step, n_steps, use_deform, record=True):

@@ -32,7 +32,11 @@ LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<5, 1>": "k_deform_f
            "k_point_fwd<0, 3>": "k_color_fwd", "k_point_fwd<2, 3>": "k_color_fwd", "k_point_bwd<2, 1>": "k_color_bwd", "k_point_fwd<0, 4>": "k_deform_vjp", "k_point_bwd<0, 1>": "k_color_bwd",
            "k_point_bwd<0, 2>": "k_sdf_bwd", "k_point_bwd<0, 3>": "k_deform_bwd", "k_point_bwd<5, 3>": "k_deform_bwd",
            "k_point_bwd<0, 4>": "k_deform_tan", "k_wgrad<0>": "k_wgrad[deform]", "k_wgrad<1>": "k_wgrad[sdf]", "k_wgrad<2>": "k_wgrad[color]",
-           "k_wgrad<0, false>": "k_wgrad[deform]", "k_wgrad<1, false>": "k_wgrad[sdf]", "k_wgrad<2, false>": "k_wgrad[color]"}
+           "k_wgrad<0, false>": "k_wgrad[deform]", "k_wgrad<1, false>": "k_wgrad[sdf]", "k_wgrad<2, false>": "k_wgrad[color]",
+           "k_query_sdf_x3r<true>": "k_query_sdf_x3", "k_query_sdf_x3r<false>": "k_query_sdf_x3", "k_deform_jvp_x3r": "k_deform_fwd_x3",
+           "k_deform_vjp_x3r": "k_deform_vjp_x3", "k_sdf_fwd_x3r<true, true>": "k_sdf_fwd_x3", "k_sdf_fwd_x3r<true, false>": "k_sdf_fwd_x3",
+           "k_sdf_fwd_x3r<false, true>": "k_sdf_fwd_x3", "k_sdf_fwd_x3r<false, false>": "k_sdf_fwd_x3", "k_color_fwd_x3r<true>": "k_color_fwd_x3",
+           "k_color_fwd_x3r<false>": "k_color_fwd_x3"}
 a, f, w = agg(d_sq), agg(d_f), agg(d_w)
 out = []
 for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
