@@ -150,7 +150,8 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
 #endif
 #ifndef XR_NO_PIN
         // keep each term's fillers next to its four MFMAs: left alone, the scheduler gathers the MFMAs into long runs and the VALU work
-        // into blocks of ~40 instructions between two of them (measured: 36.3 k -> 33.7 k cycles per 256-wide layer)
+        // into blocks of ~40 instructions between two of them (measured: 36.3 k -> 33.7 k cycles per 256-wide layer; one barrier per MFMA
+        // with the fillers dealt out by hand: 36.5 k)
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
