@@ -257,8 +257,10 @@ int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st) 
     }
     a.off[X3_COUNT] = (unsigned)X3_UNITS;
     const unsigned n = (unsigned)(X3_UNITS / 3);
-    hipLaunchKernelGGL(k_pack_x3, dim3((n + 255) / 256), dim3(256), 0, st, weff, reinterpret_cast<u32x4*>(packed_x3), a, use_deform ? 0 : 1);
-    if (int e = hip_last("pack_x3")) return e;
+    if (!use_x3r()) {       // the LDS-resident kernel's fragment order is only needed for A/B runs (ES_X3R=0)
+        hipLaunchKernelGGL(k_pack_x3, dim3((n + 255) / 256), dim3(256), 0, st, weff, reinterpret_cast<u32x4*>(packed_x3), a, use_deform ? 0 : 1);
+        if (int e = hip_last("pack_x3")) return e;
+    }
     return pack_x3r(weff, static_cast<unsigned char*>(packed_x3) + X3_UNITS * 16, use_deform, st);
 }
 
