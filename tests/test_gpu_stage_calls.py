@@ -103,6 +103,43 @@ def test_render_forward_backward_match_renderer(use_deform):
 
 
 @pytest.mark.parametrize("use_deform", [True, False])
+def test_render_forward_split_precision_stage_call(use_deform):
+    """es_render_forward with es_render_args.packed_x3 + ES_PF_X3 (no ES_PF_SAVE): the opt-in split-precision inference chain behind
+    the whole-stage C call agrees with the fp32 stage call (same inputs, same workspace layout)."""
+    r, _lib, rays, weff, packed = _setup(use_deform, N=96)
+    lib, eng, N = r.engine.lib, r.engine, rays.shape[0]
+    with torch.no_grad():
+        z = r.sample_z(rays, iter_step=1, perturb_overwrite=False)
+    S = z.shape[1]
+    var = r.model.deviation_network.variance.detach().reshape(1).contiguous()
+    wd, pd = weff.detach(), packed.detach()
+    px3 = torch.zeros(int(lib.es_packed_x3_bytes()), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.es_pack_x3(_lib.ptr(wd), _lib.ptr(px3), int(use_deform), _lib.stream_ptr()), "es_pack_x3")
+    res = []
+    for split in (False, True):
+        flags = (_lib.PF_DEFORM if use_deform else 0) | (_lib.PF_X3 if split else 0)
+        a = _lib.es_render_args()
+        out = dict(color=eng.empty(N, 3), depth=eng.empty(N, 1), weights=eng.empty(N, S), cdf=eng.empty(N, S), weight_max=eng.empty(N, 1),
+                   eik_acc=eng.zeros(2), wmax_idx=eng.empty(N, dtype=torch.int32))
+        ws = eng.empty(int(lib.es_point_workspace_floats(N * S, flags | _lib.PF_COLOR)))
+        scratch = eng.empty(int(lib.es_render_scratch_floats(N, S)))
+        a.c.rays, a.c.z, a.c.ldz, a.c.variance = _lib.ptr(rays), _lib.ptr(z), S, _lib.ptr(var)
+        a.c.N, a.c.S, a.c.sample_dist, a.c.cos_anneal = N, S, 2.0 / r.n_samples, r.get_cos_anneal_ratio(1)
+        for k, v in out.items():
+            setattr(a.c, k, _lib.ptr(v))
+        a.ws, a.scratch, a.flags = _lib.ptr(ws), _lib.ptr(scratch), flags
+        a.packed_x3 = _lib.ptr(px3) if split else None
+        _lib.check(lib.es_render_forward(C.byref(a), _lib.ptr(pd), _lib.ptr(wd), _lib.stream_ptr()), "es_render_forward")
+        torch.cuda.synchronize()
+        res.append(out)
+    f32, x3 = res
+    for k, tol_q, tol_max in (("color", 2e-4, 5e-2), ("depth", 2e-4, 5e-2), ("weights", 2e-4, 5e-2)):
+        d = (f32[k] - x3[k]).abs().flatten()
+        assert float(torch.quantile(d, 0.99)) < tol_q and float(d.max()) < tol_max, (k, float(torch.quantile(d, 0.99)), float(d.max()))
+    assert not torch.equal(f32["color"], x3["color"]), "the split-precision path must have run (results differ in the last bits)"
+
+
+@pytest.mark.parametrize("use_deform", [True, False])
 @pytest.mark.parametrize("N,block", [(96, 32), (512, 32), (512, 0)])
 def test_ray_marching_matches_renderer(use_deform, N, block):
     r, _lib, rays, weff, packed = _setup(use_deform, N=N, seed=9)
