@@ -12,13 +12,13 @@
 //     accumulator layout produces:  k-step s = (block b = s / 2, p = s % 2), lane half hi, element j  <->  feature
 //     32 b + 16 p + (j < 4 ? 4 hi + j : 8 + 4 hi + j - 4);
 //   * the weights (393 KB per 256 x 256 layer in split form) are the only LDS traffic: 24 KB per k-step (8 feature blocks x 3 planes x
-//     64 lanes x 16 B), streamed global -> registers -> LDS ring of 4 k-steps, one workgroup barrier per TWO k-steps, shared by the 4
-//     waves (one per SIMD) of the workgroup: 64 B/clk of LDS reads, 16 B/clk of L2 reads per CU.  (Direct global_load_lds_dwordx4
-//     loads need no staging registers but cost ~60 issue cycles per 1 KB piece on a wave that has no partner to hide them: measured
-//     360 cycles per k-step against 1536 of MFMA; the register-staged form is 6 loads + 6 ds_write_b128 per wave and k-step);
+//     64 lanes x 16 B), streamed global -> LDS by direct loads (global_load_lds_dwordx4, no staging registers) into a ring of 4
+//     k-steps, ONE workgroup barrier per TWO k-steps, shared by the 4 waves (one per SIMD) of the workgroup: 64 B/clk of LDS reads,
+//     16 B/clk of L2 reads per CU.  (A direct load costs ~45 issue cycles per 1 KB piece on a wave that has no partner to hide them;
+//     the register-staged alternative -- 6 global loads + 6 ds_write_b128 per wave and k-step -- was measured at twice that.)
 //   * the epilogue of layer l is spread over the k-steps of layer l+1: while the 48 MFMAs of k-step s run, the VALU builds the operand
 //     of k-step s+1 from 8 accumulator values per lane.
-// One workgroup = 256 threads = 4 waves = 128 points.  Both accumulator sets (previous layer / this layer) live in registers: ~340 of
+// One workgroup = 256 threads = 4 waves = 128 points.  Both accumulator sets (previous layer / this layer) live in registers: ~400 of
 // the 512 per lane that a one-wave-per-SIMD kernel may use.
 #include "chain_common.h"
 #include "launch.h"
