@@ -47,7 +47,8 @@ __host__ __device__ constexpr int xr_kperm(int hi, int j) { return j < 4 ? 4 * h
 //     k-step 2c+1, group 0:  read the fragments of (2c+1, group 1);  MFMAs;  all pieces landed (vmcnt 0), BARRIER
 //     k-step 2c+1, group 1:  read the fragments of (2c+2, group 0);  MFMAs
 // A pair's slots are rewritten one barrier after their last read and read one barrier after they landed; the fragments needed right
-// after a barrier are requested before the MFMAs that follow it.  A bare s_barrier + explicit vmcnt: nothing else is in flight.
+// after a barrier are requested before the MFMAs that follow it.  A bare s_barrier behind an explicit vmcnt(0): a kernel's own loads
+// and stores between two barriers (side streams, saved stacks, masks) are waited for as well, so they are issued early in a pair.
 struct FragA { u32x4 p[4][3]; };
 struct WStream {
     const u32x4* g;          // k-step 0 of the packed buffer
@@ -78,7 +79,7 @@ struct WStream {
 #pragma unroll
             for (int p = 0; p < 3; ++p) a.p[f][p] = A[((4 * grp + f) * 3 + p) * 64];
     }
-    __device__ __forceinline__ void start() {      // no other vector-memory operation may be outstanding while the stream runs
+    __device__ __forceinline__ void start() {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { piece(k, i); piece(k + 1, i); }
         landed_barrier();
