@@ -12,8 +12,10 @@ python bench.py --mode forward --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/nu
 python bench.py --split-precision --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${TAG}_split.json
 python bench.py --mode forward --split-precision --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${TAG}_forward_split.json
 python bench.py --config 5 --split-precision --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${TAG}_cfg5_frame_split.json
-cp profiles/${TAG}_cfg3.json profiles/${TAG}_cfg4.json profiles/${TAG}_cfg5_frame.json profiles/${TAG}_forward.json profiles/${TAG}_split.json profiles/${TAG}_forward_split.json profiles/${TAG}_cfg5_frame_split.json gpurun_out/
-for f in cfg3 cfg4 cfg5_frame forward split forward_split cfg5_frame_split; do python - <<PY
+python bench.py --config 3 --split-precision --steps 15 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${TAG}_cfg3_split.json
+python bench.py --config 4 --split-precision --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > profiles/${TAG}_cfg4_split.json
+cp profiles/${TAG}_cfg3.json profiles/${TAG}_cfg4.json profiles/${TAG}_cfg5_frame.json profiles/${TAG}_forward.json profiles/${TAG}_split.json profiles/${TAG}_forward_split.json profiles/${TAG}_cfg5_frame_split.json profiles/${TAG}_cfg3_split.json profiles/${TAG}_cfg4_split.json gpurun_out/
+for f in cfg3 cfg4 cfg5_frame forward split forward_split cfg5_frame_split cfg3_split cfg4_split; do python - <<PY
 import json
 b=json.load(open("profiles/${TAG}_$f.json"))
 r=b.get("roofline") or {}
