@@ -212,6 +212,13 @@ def main():
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
+    backend = os.environ.get("ES_DIST_BACKEND", "nccl")
+    if args.gpus > 1 and backend == "nccl":
+        # one rank per GPU over RCCL: fail before any rendezvous, with the numbers in the message (never fold ranks onto one device)
+        import torch
+        if torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node "
+                     f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}); RCCL needs one GPU per rank")
     if args.gpus > 1 and "RANK" not in os.environ:
         # launched directly: one rank per GPU under torch.distributed.run on this node (RCCL; rendezvous on 127.0.0.1)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -231,9 +238,14 @@ def main():
     if args.rays:
         cfg["rays"] = args.rays
     # one rank per GPU over RCCL ("nccl" on ROCm); ES_DIST_BACKEND=gloo lets the tests drive the N > 1 path on a single GPU
-    rank, world, local = parallel.init_distributed(os.environ.get("ES_DIST_BACKEND", "nccl") if args.gpus > 1 else None)
+    # ES_FORCE_DIST=1 under a one-rank torch.distributed.run: the N-rank code path (RCCL rendezvous, broadcast, barrier, the gradient
+    # all-reduce, MAX over ranks) on a single GPU -- the smoke test of the scaling runs (tests/test_gpu_bench_dp.py)
+    force_dist = args.gpus == 1 and os.environ.get("ES_FORCE_DIST") == "1" and "RANK" in os.environ
+    rank, world, local = parallel.init_distributed(backend if (args.gpus > 1 or force_dist) else None, force=force_dist)
+    dist_on = world > 1 or force_dist
     assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    local = local % max(1, torch.cuda.device_count())
+    # ES_DIST_BACKEND=gloo is the test mode in which several ranks may share one GPU (tests/test_gpu_bench_dp.py)
+    local = parallel.local_device(local, world) if (world == 1 or backend == "nccl") else local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
@@ -241,25 +253,29 @@ def main():
     renderer = EndoSurfRenderer(render_cfg(cfg), net_cfg, device=dev)
     if args.split_precision:
         renderer.engine.split_precision = True
-    trainer = Trainer(renderer, data_parallel=world > 1, schedule=args.schedule)
+    trainer = Trainer(renderer, data_parallel=dist_on, schedule=args.schedule, force_collective=force_dist)
     parallel.broadcast_parameters(trainer.params)
     scene = SyntheticScene(dev, seed=1234 + rank)
     eng = renderer.engine
     S = cfg["n_samples"] + cfg["n_importance"]
     if mode == "frame":
         # cfg5: one 640x512 frame per step, forward only, fixed 2048-ray chunks through one captured hipGraph; the frame's rows
-        # are split across the ranks (no communication; images would be gathered on the host)
+        # are split across the ranks and every step ends with the image on rank 0 (parallel.gather_frame: one all-gather of the
+        # packed colour | depth | normal slabs), as the reference's eval loop ends in one image (trainer_endosurf.py:221-240)
         H = 512
-        rows = H // world
-        frame_rays = scene.frame(H=H, W=640, t=0.5, row0=rank * rows, rows=rows)
-        n_rays = rows * 640
+        row0, rows = parallel.frame_rows(H, rank, world)
+        frame_rays = scene.frame(H=H, W=640, t=0.5, row0=row0, rows=rows)
+        n_rays = H * 640 // world        # rays per GPU (the whole job renders H x 640 rays per step)
     else:
         n_rays = cfg["rays"]
         batches = [scene.batch(n_rays) for _ in range(4)]      # resident in HBM before the timed region
 
     def step(i):
         if mode == "frame":
-            renderer.render_frames(frame_rays, iter_step=1, ray_chunk=args.chunk, perturb_overwrite=False, use_graph=not args.no_graph)
+            out = renderer.render_frames(frame_rays, iter_step=1, ray_chunk=args.chunk, perturb_overwrite=False, use_graph=not args.no_graph)
+            if world > 1:
+                out = parallel.gather_frame(out, H, 640)
+            return out
         elif mode == "train":
             trainer.update_learning_rate(i + 1)
             trainer.train_step(batches[i % len(batches)], i + 1)
@@ -268,7 +284,7 @@ def main():
                 renderer(batches[i % len(batches)]["rays"], iter_step=i + 1)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -279,7 +295,7 @@ def main():
             step(first + i)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
@@ -357,7 +373,10 @@ def main():
                        args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),
                        baseline_config=args.config, use_deform=cfg["use_deform"], split_precision=bool(args.split_precision),
                        ray_marching="all 128 proposals of every ray (data independent, as the reference)" if mode == "train" else None,
-                       with_early_exit=extra, rays_per_gpu=n_rays, samples_per_ray=S, parallelism=f"dp{world}",
+                       with_early_exit=extra, rays_per_gpu=n_rays,
+                       collective=("rccl all-reduce forced at world 1" if force_dist else (
+                           ("%s all-reduce of the flat 6.6 MB gradient bucket per step" % backend) if world > 1 and mode == "train" else (
+                               "%s all-gather of the row slabs per frame" % backend if world > 1 and mode == "frame" else None))), samples_per_ray=S, parallelism=f"dp{world}",
                        weights="reference init, torch.manual_seed(0)", algorithmic_gflop_per_ray=algorithmic_gflop_per_ray(cfg)),
                    roofline=roof, kernel_ms_per_step=timing.get("per_step_ms"), kernel_symbols=timing.get("symbols"),
                    kernel_launch_groups=timing.get("launch_groups"))
@@ -366,7 +385,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -159,7 +159,11 @@ int query_sdf16(const PointSrc& src, const float* packed, const float* weff, flo
 
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out, const int* ray_done) {
-    static const int q16_max = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 8192;      // dev switch
+#ifdef ES_DEV_SWITCHES      // dev builds only (-DES_DEV_SWITCHES): A/B runs of the tile-height threshold
+    static const int q16_max = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 8192;
+#else
+    constexpr int q16_max = 8192;         // batches up to here are latency-bound: 16-point tiles (query16.hip)
+#endif
     if (src.M > 0 && src.M <= q16_max && ld_out == 0 && ray_done == nullptr)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
     static DeviceOnce attr_done;

@@ -84,18 +84,29 @@ class FrameSet:
         self.ray_importance_maps = ray_sampling_importance_from_masks(self.masks)
         self.list_train = list(range(self.n_frames)) if list_train is None else list(list_train)
         self._host_rng = np.random.default_rng(0)
-        # per-frame sampling tables, built once (they depend on the frame only): the CDF over the colour-masked pixels, the
-        # index of the last kept pixel and (lazily) the kept-pixel lists of the uniform branch.  No host round trip per batch.
-        cm = self.color_masks[..., 0].reshape(self.n_frames, -1) == 1.0
-        imp = self.ray_importance_maps[..., 0].reshape(self.n_frames, -1)
-        # sampling over the colour-masked pixels only == sampling over all pixels with the others' weight removed; a zero weight
-        # (instead of the reference's compaction) keeps shapes static.  The 1e-5 floor is applied to kept pixels only
-        wts = torch.where(cm, imp + 1e-5, torch.zeros_like(imp))
-        self._cdf = torch.cumsum(wts / wts.sum(-1, keepdim=True), -1)
-        idx = torch.arange(cm.shape[1], device=dev)
-        self._last_kept = torch.where(cm, idx, torch.zeros_like(idx)).amax(-1)
-        self._cm = cm
+        # per-frame sampling tables (the CDF over the colour-masked pixels, the index of the last kept pixel, the kept-pixel lists of
+        # the uniform branch) are built lazily, one frame at a time, the first time a frame is drawn: no [n_frames, H*W] temporaries
+        # at construction and no host round trip per batch afterwards
+        self._tables = {}
         self._kept = {}
+
+    def _frame_tables(self, i: int):
+        """(cdf [H*W] fp32, last kept pixel [] int64, colour-mask [H*W] bool) of frame ``i``; raises if its colour mask is empty
+        (the reference's compaction would fail there as well, dataset.py:131-137)."""
+        t = self._tables.get(i)
+        if t is None:
+            cm = self.color_masks[i, ..., 0].reshape(-1) == 1.0
+            imp = self.ray_importance_maps[i, ..., 0].reshape(-1)
+            # sampling over the colour-masked pixels only == sampling over all pixels with the others' weight removed; a zero weight
+            # (instead of the reference's compaction) keeps shapes static.  The 1e-5 floor is applied to kept pixels only
+            wts = torch.where(cm, imp + 1e-5, torch.zeros_like(imp))
+            total = wts.sum()
+            if not bool(total > 0):
+                raise ValueError(f"frame {i}: the colour mask is empty, there is no pixel to sample")
+            idx = torch.arange(cm.shape[0], device=self.device, dtype=torch.int32)
+            last = torch.where(cm, idx, torch.zeros_like(idx)).amax().to(torch.int64)
+            t = self._tables[i] = (torch.cumsum(wts / total, -1), last, cm)
+        return t
 
     def get_train_batch_data_by_index(self, id_train=None, ray_batch=1024, mask_guided_ray_sampling=True, u=None) -> Dict[str, torch.Tensor]:
         if id_train is None:
@@ -105,13 +116,14 @@ class FrameSet:
         if mask_guided_ray_sampling:
             if u is None:
                 u = torch.rand(ray_batch, device=self.device)
-            sel = torch.searchsorted(self._cdf[id_train], u.reshape(-1).to(self.device).contiguous(), right=True)
+            cdf, last_kept, _ = self._frame_tables(id_train)
+            sel = torch.searchsorted(cdf, u.reshape(-1).to(self.device).contiguous(), right=True)
             # clamp like the reference (max with 0, min with last kept pixel): u -> 1 rounds to the last colour-masked pixel
-            sel = torch.minimum(sel, self._last_kept[id_train])
+            sel = torch.minimum(sel, last_kept)
         else:
             kept = self._kept.get(id_train)
             if kept is None:
-                kept = self._kept[id_train] = torch.nonzero(self._cm[id_train]).reshape(-1)      # once per frame
+                kept = self._kept[id_train] = torch.nonzero(self._frame_tables(id_train)[2]).reshape(-1)      # once per frame
             sel = kept[torch.randperm(kept.numel(), device=self.device)[:ray_batch]]
         pick = lambda a: a[id_train].reshape(self.h * self.w, -1)[sel]
         return {"color": pick(self.colors), "rays": pick(self.rays), "depth": pick(self.depths), "mask": pick(self.masks),

@@ -117,14 +117,29 @@ class Engine:
         return p
 
     def packed_x3(self, weff, use_deform: bool):
-        """The split-precision packing of ``weff`` (rebuilt when a new effective-weight buffer shows up; the cache keeps the source
-        buffer alive so that its address cannot be recycled for other weights)."""
-        c = self._x3
-        if c is None or c[1] != weff.data_ptr() or c[3] != bool(use_deform):
+        """The split-precision packing of ``weff``, one entry per ``use_deform`` (a deform model also evaluates canonical-space points
+        with the deformation network switched off), rebuilt when a new effective-weight buffer shows up.  An entry keeps its source
+        buffer alive (so that its address cannot be recycled for other weights) and the event recorded behind the packing launch:
+        a consumer on ANOTHER stream waits for it (the sampling chain of a training step runs on a side stream)."""
+        if self._x3 is None or self._x3["ptr"] != weff.data_ptr():
+            self._x3 = {"ptr": weff.data_ptr(), "src": weff.detach(), "packs": {}}
+        packs = self._x3["packs"]
+        cur = torch.cuda.current_stream(self.device)
+        e = packs.get(bool(use_deform))
+        if e is None:
             buf = torch.empty(int(self.lib.es_packed_x3_bytes()), device=self.device, dtype=torch.uint8)
             check(self.lib.es_pack_x3(ptr(weff), ptr(buf), int(use_deform), self.st()), "es_pack_x3")
-            c = self._x3 = (weff.detach(), weff.data_ptr(), buf, bool(use_deform))
-        return c[2]
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            e = packs[bool(use_deform)] = (buf, ev, cur)
+        elif e[2] != cur:
+            cur.wait_event(e[1])
+            e[0].record_stream(cur)
+        return e[0]
+
+    def x3_buffers(self):
+        """The split-precision packings currently cached (a captured hipGraph keeps them alive: it holds their raw pointers)."""
+        return [] if self._x3 is None else [self._x3["src"]] + [e[0] for e in self._x3["packs"].values()]
 
     def _use_x3(self, M: int) -> bool:
         return self.split_precision and M > 8192          # small batches are latency-bound: they stay on the 16-point fp32 tiles
@@ -313,9 +328,10 @@ class PointCtx:
         return v
 
 
-def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
+def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, like_save: bool = False) -> PointCtx:
+    """``like_save``: evaluate with the kernels a PF_SAVE call would run (the forward pass of a chunked, re-evaluated render)."""
     ctx = PointCtx(self, pts, flags, m_color)
-    if self.split_precision and not (flags & _lib.PF_SAVE) and pts.M >= self.x3_infer_min:
+    if self.split_precision and not (flags & _lib.PF_SAVE) and not like_save and pts.M >= self.x3_infer_min:
         # opt-in: the deformation- and SDF-network launches of a large no-grad evaluation in split precision (csrc/infer_x3r.hip)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
         check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(px3), ptr(weff), ptr(ctx.ws), flags, int(m_color),

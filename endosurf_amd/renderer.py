@@ -442,7 +442,10 @@ class _RenderFn(torch.autograd.Function):
                 r_, z_ = rays[i:i + chunk_rays], z[i:i + chunk_rays]
                 n_ = r_.shape[0]
                 mid = eng.mid_z(z_, sample_dist)
-                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), weff, packed, (flags & ~_lib.PF_SAVE) | _lib.PF_COLOR)
+                # same kernels as the re-evaluation in the backward (``like_save``): the loss adjoints are then taken at exactly
+                # the outputs the backward differentiates
+                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), weff, packed, (flags & ~_lib.PF_SAVE) | _lib.PF_COLOR,
+                                         like_save=True)
                 a = eng.composite_args(r_, z_, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
                 out = eng.composite_forward(a, eik_acc=eik_acc)
                 for k in ("color", "depth", "weights", "weight_max", "cdf", "wmax_idx"):
@@ -488,8 +491,8 @@ class _RenderFn(torch.autograd.Function):
         g_wmax = g_wmax.contiguous().view(-1) if g_wmax is not None else None
         sl = lambda g, i, j: g[i:j] if g is not None else None
         d_invs_acc = eng.zeros(1)
-        dweff = None
-        C = ctx.chunk_rays if ctx.chunk_rays else N
+        dweff = eng.zeros(eng.n_weff) if N == 0 else None       # an empty batch has a zero gradient, not a missing one
+        C = max(1, ctx.chunk_rays if ctx.chunk_rays else N)
         for i in range(0, N, C):
             j = min(i + C, N)
             if ctx.chunk_rays:          # re-evaluate this chunk with saving
@@ -880,7 +883,8 @@ class EndoSurfRenderer(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     static_out = chunk_forward(static_in)
-                g = self._frame_graph = {"key": key, "graph": graph, "in": static_in, "out": static_out, "weights": self._weights()}
+                g = self._frame_graph = {"key": key, "graph": graph, "in": static_in, "out": static_out, "weights": self._weights(),
+                                         "x3": self.engine.x3_buffers()}      # everything the captured launches point at stays alive
             for i in range(0, n, C):
                 m = min(C, n - i)
                 g["in"][:m].copy_(flat[i:i + m])

@@ -9,8 +9,6 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-import os as _os
-_SCHED = int(_os.environ.get("ES_SCHED", "0"))      # dev switch for stream-schedule experiments; 0 = the measured best
 LOSS_WEIGHTS = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)   # base_pull.yml:23-29
 
 
@@ -46,19 +44,13 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     # on a side stream WHILE the main stream iterates the secant (two throughput-bound kernels would only slow each other)
     main = torch.cuda.current_stream(rays.device)
     side = getattr(renderer, "_side_stream", None)
-    sched = _SCHED
     if side is None:
-        side = renderer._side_stream = torch.cuda.Stream(device=rays.device, priority=-1 if sched & 2 else 0)
-    if sched & 1:       # experiment: the sampling chain starts together with the 128-proposal marching query
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
-        ms = renderer._march_begin(rays)
-    else:
-        ms = renderer._march_begin(rays)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
+        side = renderer._side_stream = torch.cuda.Stream(device=rays.device)
+    # (starting the sampling chain together with the marching query, or on a high-priority stream, was measured and is slower: DESIGN 4)
+    ms = renderer._march_begin(rays)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb)
     d_i = renderer._march_refine(ms)
     aux_x, aux_t, valid_sn = renderer._train_aux_points(rays, depth_gt, mask_gt, d_i, surf_neig_rad, u_neigh)    # one launch
     eod_pts = aux_x[:N]
@@ -303,8 +295,9 @@ class Trainer:
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
                  loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
-                 schedule: str = None, flat_adam: bool = True):
+                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False):
         self.renderer = renderer
+        self.force_collective = bool(force_collective)      # issue the gradient all-reduce even at world size 1 (RCCL smoke test)
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
         # Adam with the reference's defaults (trainer_endosurf.py:70); on the GPU the single-kernel "fused" implementation
@@ -355,7 +348,7 @@ class Trainer:
             if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update
                 from .parallel import allreduce_flat
                 g = self.optimizer.flat_grad(include_variance=True)
-                world = allreduce_flat(g)
+                world = allreduce_flat(g, force=self.force_collective)
                 self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
             else:
                 self.optimizer.step()

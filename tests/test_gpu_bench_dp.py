@@ -106,3 +106,77 @@ torch.distributed.destroy_process_group()
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["maxdiff"] == 0.0, d                    # same summed bucket, same update on every rank
     assert d["moved"] > 1e-4, d
+
+
+def test_rccl_world1_trainer_allreduce():
+    """The RCCL path itself, on one GPU: backend "nccl" (= RCCL on ROCm) at world size 1, parameter broadcast, and a data-parallel
+    Trainer whose flat 6.6 MB gradient bucket goes THROUGH the all-reduce (``force_collective``): librccl loads, the communicator
+    initialises, the collective runs on the bucket FlatAdam consumes.  Sum over one rank = identity, so the trained parameters must
+    equal those of a non-distributed run bit for bit (deterministic reductions)."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["ES_REPO"]); sys.path.insert(0, os.path.join(os.environ["ES_REPO"], "tests"))
+import torch
+import torch.distributed as dist
+from endosurf_amd import parallel
+from endosurf_amd.trainer import Trainer, SyntheticScene
+from gpu_util import renderer_for
+rank, world, local = 0, 1, 0
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+def run(dp):
+    r = renderer_for(5, "trained", True)
+    r.engine.deterministic = True
+    tr = Trainer(r, lr=1e-3, data_parallel=dp, force_collective=dp)
+    if dp:
+        parallel.broadcast_parameters(tr.params)
+    sc = SyntheticScene("cuda", seed=100)
+    for it in range(2):
+        tr.update_learning_rate(7000 + it)
+        tr.train_step(sc.batch(256), 20000 + it)
+    return r.model._flat.detach().clone()
+a = run(True)
+g = torch.full((1654951,), 2.0, device="cuda")
+w = parallel.allreduce_flat(g, force=True)
+torch.cuda.synchronize()
+b = run(False)
+print(json.dumps(dict(world=w, bucket_ok=bool((g == 2.0).all()), maxdiff=float((a - b).abs().max()), finite=bool(torch.isfinite(a).all()))))
+dist.destroy_process_group()
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "w.py")
+        open(script, "w").write(code)
+        env = dict(os.environ, ES_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["world"] == 1 and d["bucket_ok"] and d["finite"], d
+    assert d["maxdiff"] == 0.0, d
+
+
+def test_bench_rccl_world1_line():
+    """bench.py under torch.distributed.run with ONE rank and the default backend: the whole N-rank code path (RCCL rendezvous,
+    broadcast, barrier, MAX all-reduce of the time) runs on the box's single GPU and prints its JSON line."""
+    env = {k: v for k, v in os.environ.items() if k != "ES_DIST_BACKEND"}
+    env["ES_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["collective"] == "rccl all-reduce forced at world 1"
+
+
+def test_bench_more_ranks_than_gpus_fails_fast():
+    """``--gpus N`` with fewer than N GPUs on the node exits at once with a clear message (it used to fold ranks onto one device)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ES_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode != 0
+    assert f"only {n - 1} GPU(s) visible" in out.stderr, out.stderr[-2000:]

@@ -189,6 +189,13 @@ def test_bench_work_model_and_self_launch(monkeypatch):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("ES_DIST_BACKEND", raising=False)
+    # fewer GPUs than ranks: exits at once with the numbers in the message, nothing is launched (it used to fold ranks onto one GPU)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 2 GPU(s) visible" in str(e.value.code) and "cmd" not in seen
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0

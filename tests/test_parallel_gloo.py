@@ -82,3 +82,67 @@ def test_allreduce_flat_sums_one_bucket():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, 2, 3.0, 3.0), (1, 2, 3.0, 3.0)]
+
+
+def _gather_worker(rank, world, port, q, H, W):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from endosurf_amd import parallel
+    parallel.init_distributed("gloo")
+    r0, rows = parallel.frame_rows(H, rank, world)
+    # pixel (y, x) carries the value 1000 y + x in every channel (+ channel index): the assembled frame is checked entry by entry
+    yy, xx = torch.meshgrid(torch.arange(r0, r0 + rows, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    base = (1000.0 * yy + xx).reshape(-1, 1)
+    parts = {"color": base + torch.arange(3.0), "depth": base + 10.0, "normal": base + 20.0 + torch.arange(3.0)}
+    out = parallel.gather_frame(parts, H, W)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in out.items()})
+    else:
+        assert out is None
+        q.put(None)
+    dist.destroy_process_group()
+
+
+def test_gather_frame_world2_uneven_rows():
+    """cfg5 on N ranks: rank 0 ends with ONE [H, W, C] image per output, assembled from the ranks' row slabs (H odd: the slabs differ)."""
+    import numpy as np
+    H, W = 7, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q, H, W)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out = [r for r in res if r is not None]
+    assert len(out) == 1
+    out = out[0]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    base = 1000.0 * yy + xx
+    assert out["color"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1) and out["normal"].shape == (H, W, 3)
+    for c in range(3):
+        assert np.array_equal(out["color"][..., c], base + c) and np.array_equal(out["normal"][..., c], base + 20 + c)
+    assert np.array_equal(out["depth"][..., 0], base + 10)
+
+
+def test_gather_frame_single_process_and_row_split():
+    from endosurf_amd import parallel
+    assert [parallel.frame_rows(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 64)]
+    assert [parallel.frame_rows(7, r, 4) for r in range(4)] == [(0, 2), (2, 2), (4, 2), (6, 1)]
+    assert parallel.frame_rows(3, 3, 4) == (3, 0)
+    parts = {"color": torch.arange(24.0).reshape(8, 3), "depth": torch.arange(8.0).reshape(8, 1)}
+    out = parallel.gather_frame(parts, 2, 4)
+    assert out["color"].shape == (2, 4, 3) and torch.equal(out["color"].reshape(8, 3), parts["color"])
+    assert torch.equal(out["depth"].reshape(8, 1), parts["depth"])
+
+
+def test_local_device_fails_fast_instead_of_folding(monkeypatch):
+    """A rank without a GPU of its own must raise with the numbers in the message (bench.py folded 8 ranks onto fewer GPUs)."""
+    import pytest
+    from endosurf_amd import parallel
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert parallel.local_device(1, 8) == 1
+    with pytest.raises(RuntimeError, match="only 2 GPU"):
+        parallel.local_device(2, 8)
