@@ -69,19 +69,35 @@ def algorithmic_gflop_per_ray(c):
     return dict(upsample=f_up / 1e9, render_core_forward=f_core / 1e9, ray_marching=f_march / 1e9, train_step=(f_up + 3 * f_core + f_march) / 1e9)
 
 
-def kernel_macs(name, use_deform):
-    """Executed MACs per point of each timed kernel.  The deformation network runs as value + JVP (J d) rows (2D), one VJP sweep
-    (J^T g_c, D) and, in the backward, one tangent sweep (J gbar_o, D); SDF 2S (value + reverse / tangent + reverse), colour C; weight
-    gradients the same again; the SDF queries D + S.  Launches whose tiles may exit early are not counted as work."""
+def kernel_macs(name, use_deform, executed=True):
+    """MACs per point of each timed kernel.  The deformation network runs as value + JVP (J d) rows (2D), one VJP sweep (J^T g_c, D) and,
+    in the backward, one tangent sweep (J gbar_o, D); SDF 2S (value + reverse / tangent + reverse), colour C; weight gradients the same
+    again; the SDF queries D + S.  Launches whose tiles may exit early are not counted as work.
+
+    ``executed`` (default): the MACs the kernels ISSUE.  The SDF network's last layer is [257 x 256]; a query needs only its sdf row
+    (query.hip: one 256-MAC dot product instead of 65 792 MACs), the analytic reverse sweep of k_sdf_fwd starts from that one row, the
+    tangent sweep of k_sdf_bwd ends at tau_8 and the g_c-path weight gradient of the last layer is a column sum: the nominal SURVEY 8d
+    figures (``executed=False``: D, S, C per pass) overstate these kernels by 65 536 / 65 792 MACs per point (6.5 % of a query)."""
     D = MAC_D if use_deform else 0
-    return {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_query_sdf_x3": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D, "k_sdf_fwd": 2 * MAC_S,
-            "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D, "k_deform_bwd": 2 * MAC_D,
-            "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C,
-            "k_wgrad_x3[deform]": 3 * MAC_D, "k_wgrad_x3[sdf]": 2 * MAC_S, "k_wgrad_x3[color]": MAC_C,
-            "k_deform_fwd_x3": 2 * MAC_D, "k_deform_vjp_x3": MAC_D, "k_sdf_fwd_x3": 2 * MAC_S, "k_color_fwd_x3": MAC_C}.get(name)
+    S8 = 257 * 256                     # MACs of the SDF network's last layer (sdf row + 256 feature rows)
+    cut = {"k_query_sdf": S8 - 256, "k_query_sdf16": S8 - 256, "k_query_sdf_x3": S8 - 256,      # sdf row only
+           "k_sdf_fwd": S8 - 256, "k_sdf_fwd_x3": S8 - 256,      # reverse sweep: rho_7 = softplus'(z_7) . W8[0, :], 256 multiplies
+           "k_sdf_bwd": S8,                                      # tangent sweep stops at tau_8; reverse: SR8F (65 536) + the sdf row (256)
+           "k_wgrad[sdf]": S8 - 256, "k_wgrad_x3[sdf]": S8 - 256}      # g_c-path pair of the last layer: column sums of tau_8
+    nominal = {"k_query_sdf": D + MAC_S, "k_query_sdf16": D + MAC_S, "k_query_sdf_x3": D + MAC_S, "k_deform_fwd": 2 * MAC_D, "k_deform_vjp": MAC_D,
+               "k_sdf_fwd": 2 * MAC_S, "k_color_fwd": MAC_C, "k_color_bwd": MAC_C, "k_sdf_bwd": 2 * MAC_S, "k_deform_tan": MAC_D,
+               "k_deform_bwd": 2 * MAC_D, "k_wgrad[deform]": 3 * MAC_D, "k_wgrad[sdf]": 2 * MAC_S, "k_wgrad[color]": MAC_C,
+               "k_wgrad_x3[deform]": 3 * MAC_D, "k_wgrad_x3[sdf]": 2 * MAC_S, "k_wgrad_x3[color]": MAC_C,
+               "k_deform_fwd_x3": 2 * MAC_D, "k_deform_vjp_x3": MAC_D, "k_sdf_fwd_x3": 2 * MAC_S, "k_color_fwd_x3": MAC_C,
+               "k_deform_tan_x3": MAC_D, "k_deform_bwd_x3": 2 * MAC_D, "k_color_bwd_x3": MAC_C, "k_sdf_bwd_x3": 2 * MAC_S}.get(name)
+    if nominal is None:
+        return None
+    if name.endswith("_x3") and name[:-3] in cut:
+        cut[name] = cut[name[:-3]]
+    return nominal - (cut.get(name, 0) if executed else 0)
 
 
-def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
+def cpu_baseline(n_rays=256, min_seconds=10.0, max_iters=40, threads=16, extra_128=True):
     """The oracle (CPU restatement of the reference op sequence, torch-CPU fp32 + autograd) timed on this box's host cores
     on a bounded sample of the same workload: full training steps at ``n_rays`` rays.  16 intra-op threads: at these tensor
     sizes (8 192 points x 256 features per GEMM) torch-CPU is fastest there (measured 8/16/32/64/128 threads on the 2 x 64-core
@@ -118,16 +134,22 @@ def cpu_baseline(n_rays=128, min_seconds=10.0, max_iters=40, threads=16):
     dt = (time.perf_counter() - t0) / it
     cores = torch.get_num_threads()
     torch.set_num_threads(prev_threads)
+    extra = None
+    if extra_128 and n_rays != 128:       # rounds 1-2 reported this sample size: kept as an extra so the series stays comparable
+        e = cpu_baseline(128, min_seconds=4.0, max_iters=12, threads=threads, extra_128=False)
+        extra = dict(value=e["value"], n_rays=128, sample=e["sample"])
     return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
-                sample=f"{it} full training steps (config 2 networks and loss) of the CPU oracle at {n_rays} rays x 64 samples (a 128-ray sample of "
-                       f"the 1024-ray batch; BASELINE config 1 is the same step at 256 rays), torch-CPU fp32 + autograd, {dt:.2f} s/step",
-                config=dict(n_rays=n_rays, samples_per_ray=64, threads=cores),
+                sample=f"{it} full training steps (config 2 networks and loss) of the CPU oracle at {n_rays} rays x 64 samples "
+                       f"({'BASELINE config 1: the 256-ray batch' if n_rays == 256 else 'a sample of the 1024-ray batch'}), "
+                       f"torch-CPU fp32 + autograd, {dt:.2f} s/step",
+                config=dict(n_rays=n_rays, samples_per_ray=64, threads=cores), at_128_rays=extra,
                 reference_in_build_container="profiles/reference_cpu.json: the reference itself (imported unmodified), 8 vCPU build container")
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of a kernel symbol from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/pmc_summary.py), launch-weighted over its launch sizes; None if absent."""
+def pmc_info(symbol):
+    """Counters of a kernel symbol from the newest committed rocprofv3 PMC summary that has it (profiles/*_pmc_summary.json; separate
+    --pmc passes, tools/pmc_summary.py), over all its launch sizes: HBM bytes per logical launch (FETCH_SIZE x 2 + WRITE_SIZE),
+    cycle-weighted MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)) and cycles per logical launch; None if absent."""
     import glob
     # newest summary that has the symbol (by name: the round tags sort; mtimes are meaningless on a fresh copy of the tree)
     rows, used = [], None
@@ -138,13 +160,20 @@ def pmc_traffic(symbol):
             break
     if not rows:
         return None
-    # one timed launch may be two kernels (the halves of the deformation launch, point_fwd.hip): bytes per logical launch =
-    # total bytes / launches of the most frequent instantiation
-    total = sum(r["hbm_bytes"] * r["launches"] for r in rows)
+    # one timed launch may be two kernels (the halves of the deformation launch, point_fwd.hip): per logical launch =
+    # totals / launches of the most frequent instantiation
     by_kernel = {}
     for r in rows:
         by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0) + r["launches"]
-    return total / max(by_kernel.values()), os.path.basename(used)
+    n = max(by_kernel.values())
+    cyc = sum(r["cycles"] * r["launches"] for r in rows)
+    return dict(hbm_bytes=sum(r["hbm_bytes"] * r["launches"] for r in rows) / n, cycles=cyc / n,
+                mfma_util=sum(r["mfma_util"] * r["cycles"] * r["launches"] for r in rows) / cyc if cyc else None, source=os.path.basename(used))
+
+
+def pmc_traffic(symbol):
+    p = pmc_info(symbol)
+    return (p["hbm_bytes"], p["source"]) if p else None
 
 
 def kernel_timing(eng, step, first_step, n_steps, use_deform, record=True):
@@ -161,21 +190,23 @@ def kernel_timing(eng, step, first_step, n_steps, use_deform, record=True):
         return {}
     rec = eng.timing_drain()
     eng.timing_enable(False)
-    sym = {}              # symbol -> [total ms, launches, total flops]
+    sym = {}              # symbol -> [total ms, launches, total executed flops, total nominal flops]
     groups = {}           # (symbol, rows) -> [total ms, launches]
     for name, rows, ms in rec:
-        macs = kernel_macs(name, use_deform)
-        s = sym.setdefault(name, [0.0, 0, 0.0])
-        s[0] += ms; s[1] += 1; s[2] += 2.0 * macs * rows if macs else 0.0
+        macs, nom = kernel_macs(name, use_deform), kernel_macs(name, use_deform, executed=False)
+        s = sym.setdefault(name, [0.0, 0, 0.0, 0.0])
+        s[0] += ms; s[1] += 1; s[2] += 2.0 * macs * rows if macs else 0.0; s[3] += 2.0 * nom * rows if nom else 0.0
         g = groups.setdefault((name, rows), [0.0, 0])
         g[0] += ms; g[1] += 1
     out = {"per_step_ms": {k: round(v[0] / n_steps, 4) for k, v in sorted(sym.items(), key=lambda kv: -kv[1][0])}}
     out["flops_per_step"] = sum(v[2] for v in sym.values()) / n_steps
+    out["nominal_flops_per_step"] = sum(v[3] for v in sym.values()) / n_steps
     cand = [(v[0], k) for k, v in sym.items() if v[2] > 0]
     if cand:
         _, name = max(cand)             # dominant kernel = the SYMBOL with the largest total time (as rocprofv3 --stats ranks them)
-        tot, cnt, fl = sym[name]
+        tot, cnt, fl, fl_nom = sym[name]
         out["dominant"] = dict(kernel=name, avg_launch_ms=tot / cnt, launches=cnt, flops_per_launch=fl / cnt, tflops=fl / (tot * 1e-3) / 1e12,
+                               nominal_flops_per_launch=fl_nom / cnt, nominal_tflops=fl_nom / (tot * 1e-3) / 1e12,
                                share_of_timed_kernel_time=tot / sum(v[0] for v in sym.values()))
     out["symbols"] = [dict(kernel=k, launches_per_step=v[1] / n_steps, ms_per_step=round(v[0] / n_steps, 4),
                            tflops=round(v[2] / (v[0] * 1e-3) / 1e12, 2) if v[2] else None) for k, v in sorted(sym.items(), key=lambda kv: -kv[1][0])]
@@ -341,18 +372,32 @@ def main():
         roof = None
         if timing.get("dominant"):
             d = timing["dominant"]
-            tr = pmc_traffic(d["kernel"])
+            pm = pmc_info(d["kernel"])
+            same_as_pmc = mode == "train" and args.config == 2 and not args.rays
+            tr = (pm["hbm_bytes"], pm["source"]) if pm else None
             e2e = flops_per_step / (ms * 1e-3) / 1e12
+            e2e_nom = timing.get("nominal_flops_per_step", 0.0) * (flops_per_step / max(timing.get("flops_per_step", 0.0), 1e-30)) / (ms * 1e-3) / 1e12
             x3 = "_x3" in d["kernel"]
             # a split-precision kernel issues SIX bf16 MACs per fp32-equivalent MAC: price it against the bf16 matrix peak
             ach, peak = (d["tflops"] * 6.0, PEAK_BF16_MFMA) if x3 else (d["tflops"], PEAK_F32_MFMA)
             roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
                         traffic=tr[0] if tr else None, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                         traffic_source=tr[1] if tr else None, kernel=d["kernel"],
+                        work="EXECUTED MACs (the MACs the kernel issues; kernel_macs in bench.py) x 2 x points per launch",
+                        nominal=dict(achieved=d["nominal_tflops"] * (6.0 if x3 else 1.0), frac=d["nominal_tflops"] * (6.0 if x3 else 1.0) / peak,
+                                     flops_per_launch=d["nominal_flops_per_launch"],
+                                     note="SURVEY 8d per-point figures (D, S, C per pass) incl. the last-layer rows this kernel never issues"),
+                        # counters of the same symbol from the committed PMC passes (profiles/): MFMA-busy share of the SIMD cycles and
+                        # the HBM rate its traffic means at the launch duration measured here
+                        # (rates only where the PMC passes profiled this very workload: the headline configuration)
+                        mfma_util=pm["mfma_util"] if pm else None,
+                        hbm_gbps=(pm["hbm_bytes"] / (d["avg_launch_ms"] * 1e-3) / 1e9) if pm and same_as_pmc else None,
+                        clock_ghz_from_pmc_cycles=(pm["cycles"] / (d["avg_launch_ms"] * 1e-3) / 1e9) if pm and same_as_pmc else None,
                         kernel_choice="the kernel SYMBOL with the largest total time per step (all its launch sizes together)",
                         avg_launch_ms=d["avg_launch_ms"], launches=d["launches"], flops_per_launch=d["flops_per_launch"],
                         fp32_equivalent_tflops=d["tflops"], share_of_timed_kernel_time=d["share_of_timed_kernel_time"],
                         end_to_end=dict(achieved=e2e, frac=e2e / PEAK_F32_MFMA, unit="TFLOP/s", flops_per_step=flops_per_step,
+                                        nominal_achieved=e2e_nom, nominal_frac=e2e_nom / PEAK_F32_MFMA,
                                         note="executed fp32-equivalent GEMM FLOPs of one step (2 x MACs x points of every timed launch) / "
                                              "ms_per_step, against the fp32 MFMA peak (a split-precision run can exceed it: its GEMMs run on "
                                              "the bf16 pipes)"),

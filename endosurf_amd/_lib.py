@@ -75,7 +75,9 @@ PROTOTYPES = {
     "es_point_workspace_floats": (C.c_int64, [_I, _I]),
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
+    "es_color_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _P]),
     "es_point_forward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P]),
+    "es_point_backward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "es_wgrad_scratch_floats": (C.c_int64, []),
     "es_point_backward_det": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -97,7 +99,7 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 

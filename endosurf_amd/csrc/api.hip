@@ -22,8 +22,9 @@ int variance_terms(const float* variance, const float* d_invs_acc, float* s_val,
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st,
                   const void* packed_x3 = nullptr);
+int color_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
-                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st);
+                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st, const void* packed_x3 = nullptr);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
 size_t wgrad_det_floats();
 int train_loss(const LossArgs& a, hipStream_t st);
@@ -223,14 +224,32 @@ int es_point_forward(const es_points* pts, const float* packed, const float* wef
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     return point_forward(to_src(pts), packed, weff, ws, flags, m_color, (hipStream_t)stream);
 }
+int es_color_forward(const es_points* pts, const float* packed, const float* weff, float* ws, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
+    ES_REQUIRE(pts->mode == 0 && pts->dirs, "es_color_forward takes explicit points with their view directions");
+    return color_forward(to_src(pts), packed, weff, ws, (hipStream_t)stream);
+}
 int es_point_forward_x3(const es_points* pts, const float* packed, const void* packed_x3, const float* weff, float* ws, int flags, int m_color,
                         void* stream) {
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(packed && packed_x3 && weff && (ws || pts->M == 0), "null buffer");
-    ES_REQUIRE(!(flags & ES_PF_SAVE), "es_point_forward_x3 is the no-grad evaluation (no ES_PF_SAVE)");
     ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
     if (int e = check_mcolor(pts, flags, m_color)) return e;
-    return point_forward(to_src(pts), packed, weff, ws, flags | ES_PF_X3, m_color, (hipStream_t)stream, packed_x3);
+    // no-grad evaluation: ES_PF_X3; with ES_PF_SAVE: the split-precision TRAINING chain (ES_PF_X3_CHAIN; backward: es_point_backward_x3)
+    const int mode = (flags & ES_PF_SAVE) ? ES_PF_X3_CHAIN : ES_PF_X3;
+    return point_forward(to_src(pts), packed, weff, ws, (flags & ~(ES_PF_X3 | ES_PF_X3_CHAIN)) | mode, m_color, (hipStream_t)stream, packed_x3);
+}
+int es_point_backward_x3(const es_points* pts, const float* packed, const void* packed_x3, const float* weff, float* ws, int flags, int m_color,
+                         const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, float* wg_scratch, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(flags & ES_PF_SAVE, "es_point_backward_x3 needs a workspace produced by es_point_forward_x3 with ES_PF_SAVE");
+    ES_REQUIRE(packed && packed_x3 && weff && dweff && (pts->M == 0 || (ws && d_sdf && d_go)), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    flags |= ES_PF_X3_CHAIN | ES_PF_X3;          // chain kernels of the split-precision family, weight-gradient GEMMs in split precision
+    if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream, packed_x3)) return e;
+    return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, wg_scratch, (hipStream_t)stream);
 }
 
 int es_point_backward(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
@@ -358,6 +377,7 @@ int es_render_forward(const es_render_args* a, const float* packed, const float*
     if (a->c.N == 0) return ST_OK;
     hipStream_t st = (hipStream_t)stream;
     if (int e = mid_z(a->c.z, a->c.ldz, a->c.N, a->c.S, a->c.sample_dist, a->scratch, st)) return e;
+    if ((flags & ES_PF_X3) && (flags & ES_PF_SAVE) && a->packed_x3) flags = (flags & ~ES_PF_X3) | ES_PF_X3_CHAIN;      // training chain
     if (int e = point_forward(ps, packed, weff, a->ws, flags, 0, st, a->packed_x3)) return e;
     return composite(render_composite_args(a, flags), 0, st);
 }
@@ -371,7 +391,8 @@ int es_render_backward(const es_render_args* a, const float* packed, const float
     hipStream_t st = (hipStream_t)stream;
     const CompositeArgs c = render_composite_args(a, flags);
     if (int e = composite(c, 1, st)) return e;
-    if (int e = point_backward_chains(ps, packed, weff, a->ws, flags, 0, c.d_sdf, c.d_go, c.d_rgb, st)) return e;
+    if ((flags & ES_PF_X3) && a->packed_x3) flags |= ES_PF_X3_CHAIN;       // the forward of the same arguments ran the split-precision chain
+    if (int e = point_backward_chains(ps, packed, weff, a->ws, flags, 0, c.d_sdf, c.d_go, c.d_rgb, st, a->packed_x3)) return e;
     return point_wgrad(ps.M, a->ws, flags, 0, c.d_sdf, dweff, a->wg_scratch, st);
 }
 

@@ -20,19 +20,13 @@ namespace es {
 constexpr int XI_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + (128 * XR_ENC_LD + 8 * 256 + 3 * 256 + 4) * 4;
 static_assert(XI_LDS_BYTES <= 160 * 1024, "LDS carve");
 
-// mask bit of register r of feature block b inside the 128-bit word of a (layer, point, lane half)
-__device__ __forceinline__ void mask_set(u32x4& mk, int b, int r, bool m) { mk[b >> 1] |= (m ? 1u : 0u) << ((b & 1) * 16 + r); }
-__device__ __forceinline__ bool mask_get(const u32x4& mk, int b, int r) { return (mk[b >> 1] >> ((b & 1) * 16 + r)) & 1u; }
-
-// the element of the VALUE column of this lane's point: lanes 0-15 of a lane half keep their own, lanes 16-31 get their partner's
-// (v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first operand with the even rows of its second)
-__device__ __forceinline__ float value_row(float z) {
-    return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false)[0]);
-}
-
 // ---- value + tangent ------------------------------------------------------------------------------------------------------------
+// SAVE (training): the layer inputs u_0 (encoding rows) and u_1 .. u_8 go to WS_D_U0 / WS_D_U, row 2 p = value, row 2 p + 1 = tangent
+// of point p, row-major -- the X operands of the weight-gradient GEMMs (wgrad.hip), same layout as point_fwd.hip's deform_fwd_tile.
+template <bool SAVE>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
-                                                                float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks, int Mp) {
+                                                                float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks,
+                                                                float* __restrict__ U0, float* __restrict__ U, int Mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     float* encs = reinterpret_cast<float*>(ldsr + XR_RING * XR_CHUNK_BYTES);      // [128 columns][68]
     float* biasL = encs + 128 * XR_ENC_LD;                                         // [8 layers][256]
@@ -78,6 +72,12 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
         for (int k = 52; k < 64; ++k) erow[k] = 0.f;
     }
     __syncthreads();
+    const size_t urow = (size_t)point * 2 + (tan ? 1 : 0);     // this lane's row of the 2-rows-per-point stacks
+    const size_t rows2 = (size_t)Mp * 2;
+    if (SAVE) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) st4(U0 + urow * 64 + 32 * hi + k, erow[32 * hi + k], erow[32 * hi + k + 1], erow[32 * hi + k + 2], erow[32 * hi + k + 3]);
+    }
     WStream ws;
     ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane;
     ws.start();
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
         const bool skip = l == 4;                          // IDR skip: input of layer 4 = [h(204) | enc(52)] (1/sqrt2 folded into W4)
         u32x4 mk = {0u, 0u, 0u, 0u};
         init(C, l);
-        gemm_r<16>(C, ws, [&](int s, int j) -> float {
+        float* Ul = U + ((size_t)(l - 1) * rows2 + urow) * 256 + 4 * hi;      // u_l = this GEMM's operand
+        gemm_rs<16>(C, ws, [&](int s, int j) -> float {
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float z = P[b][4 * q + i];
@@ -111,23 +112,30 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
             const float h = m ? z : 0.f;
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
-        });
+        }, NoSide(), [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Ul, s, v); });
         if (!tan && point < Mp) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
         copy8(P, C);
     }
     {   // x_c = x + W8 relu(z_7) + b8 on the value columns, v = d + W8 (mask_7 . tau_7) on the tangent columns
         u32x4 mk = {0u, 0u, 0u, 0u};
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        float* U8 = U + ((size_t)7 * rows2 + urow) * 256 + 4 * hi;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
-                const float z = P[b][r];
-                const bool m = value_row(z) > 0.f;
-                mask_set(mk, b, r, m);
-                const float h = m ? z : 0.f;
-                d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
+            for (int q = 0; q < 4; ++q) {
+                float h4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i, f = 32 * b + 8 * q + 4 * hi + i;
+                    const float z = P[b][r];
+                    const bool m = value_row(z) > 0.f;
+                    mask_set(mk, b, r, m);
+                    const float h = m ? z : 0.f;
+                    h4[i] = h;
+                    d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
+                }
+                if (SAVE) st4(U8 + 32 * b + 8 * q, h4[0], h4[1], h4[2], h4[3]);
             }
         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
         if (point < Mp) {
@@ -143,9 +151,12 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
 }
 
 // ---- reverse sweep ---------------------------------------------------------------------------------------------------------------
+// SAVE (training): the adjoints r_7 .. r_0 of the pre-activations go to WS_D_R ([8][Mp][256] row-major): paired with the tangent sweep
+// of the backward pass (tau_l, train_x3r.hip) they are the weight gradient of the g_o path.
+template <bool SAVE>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                                 const float* __restrict__ ws_gc, float* __restrict__ ws_go,
-                                                                const u32x4* __restrict__ masks, int Mp) {
+                                                                const u32x4* __restrict__ masks, float* __restrict__ R, int Mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     float* adj = reinterpret_cast<float*>(ldsr + XR_RING * XR_CHUNK_BYTES);       // [128 points][68]: adjoint of the 52 encoding inputs
     float* w8L = adj + 128 * XR_ENC_LD + 8 * 256;                                  // [3][256]
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const int point = blockIdx.x * 128 + wave * 32 + n;
-    const bool live = point < Mp;
+    constexpr bool live = true;                                // Mp is a multiple of 128 (workspace.h): every point of a block is a workspace row
     float* arow = adj + (wave * 32 + n) * XR_ENC_LD;
     float x[3], t, d[3];
     load_point(src, point, x, t, d);
@@ -176,12 +187,16 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     };
     // r_7 = mask_7 . (W8^T g_c)  ->  adjoint of h_6 = W_7^T r_7
     zero(C);
-    gemm_r<16>(C, ws, [&](int s, int j) -> float {
+    float* Rrow = R + (size_t)(live ? point : 0) * 256 + 4 * hi;       // + l Mp 256: r_l of this lane's point
+    const size_t rstride = (size_t)Mp * 256;
+    int lsave = 7;
+    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * rstride, s, v); };      // (Mp is a multiple of 128: every point of the block is a row)
+    gemm_rs<16>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], g[0], fmaf(w8L[256 + f], g[1], w8L[512 + f] * g[2]));
         return mask_get(mk, b, 4 * q + i) ? v : 0.f;
-    });
+    }, NoSide(), rsink);
     copy8(P, C);
     // layers 6 .. 1: r_l = mask_l . (adjoint of h_l),  adjoint of h_{l-1} = W_l^T r_l
 #pragma unroll 1
@@ -201,17 +216,24 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             return mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;      // layer 3: mask bits of features >= 204 are 0
         };
-        if (l == 3) gemm_r<14>(C, ws, val);     // 204 outputs of layer 3: 14 k-steps (the rest is zero padding in DR3)
-        else gemm_r<16>(C, ws, val);
+        lsave = l;
+        if (l == 3) {                           // 204 outputs of layer 3: 14 k-steps (the rest is zero padding in DR3)
+            gemm_rs<14>(C, ws, val, NoSide(), rsink);
+            if (SAVE) {                         // features 224 .. 255 of r_3 are zero like 204 .. 223
+                const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                st_kstep(Rrow + 3 * rstride, 14, z8); st_kstep(Rrow + 3 * rstride, 15, z8);
+            }
+        } else gemm_rs<16>(C, ws, val, NoSide(), rsink);
         copy8(P, C);
     }
     // r_0 = mask_0 . (adjoint of h_0);  adjoint of the encoding += W_0^T r_0 (52 outputs: accumulator group 0 only)
     mk = masks[mrow];
     zero(C);
-    gemm_r<16, 1>(C, ws, [&](int s, int j) -> float {
+    lsave = 0;
+    gemm_rs<16, 1>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;
-    });
+    }, NoSide(), rsink);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -263,8 +285,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const int point = blockIdx.x * 128 + wave * 32 + n;
-    const bool live = point < Mp;
-    const bool wave_live = blockIdx.x * 128 + wave * 32 < Mp;                      // wave-uniform: the stack has no room for dead waves
+    constexpr bool live = true;                                // Mp is a multiple of 128 (workspace.h): every point of a block is a workspace row
+    constexpr bool wave_live = true;
     float* erow = encs + (wave * 32 + n) * XS_ENC_LD;
     float x[3];
     if (DEFORM) {
@@ -438,11 +460,15 @@ constexpr int XC_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XC_FRING_BYTES + (8 * 25
 constexpr int XC_K_0S = 0, XC_K_0F = 6, XC_K_4S = 6 + 16 + 48 + 16, XC_K_4F = XC_K_4S + 6;     // logical k-steps of CF0S, CF0F, CF4S, CF4F
 static_assert(xr_kg(35) == 6 && xr_kg(41) == 6 && XC_K_4F == 92, "colour stream layout");
 
-template <bool DEFORM>
+// SAVE (training; launched over whole 128-point blocks, every point of which is a workspace row): the small part of the input goes to
+// WS_C_IN ([Mp][128], 96 written), the layer inputs h_1 .. h_8 to WS_C_H (row-major, the X operands of the weight-gradient GEMMs) and
+// the ReLU masks to WS_C_MASK in this family's layout (128 bits per (layer, point, lane half), read by k_color_bwd_x3r).
+template <bool DEFORM, bool SAVE>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                                const float* __restrict__ ws_xc, const float* __restrict__ ws_v,
                                                                const float* __restrict__ ws_gc, const float* __restrict__ ws_feat,
-                                                               float* __restrict__ ws_rgb, int Mcp) {
+                                                               float* __restrict__ ws_rgb, float* __restrict__ CIN, float* __restrict__ CH,
+                                                               u32x4* __restrict__ masks, int Mcp, int Mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     unsigned char* fring = ldsr + XR_RING * XR_CHUNK_BYTES;
     float* biasL = reinterpret_cast<float*>(fring + XC_FRING_BYTES);               // [8][256]
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const int point = blockIdx.x * 128 + wave * 32 + n;
-    const bool live = point < Mcp;
+    const bool live = SAVE || point < Mcp;
     const size_t pl = live ? point : 0;
     float xc[3], gc[3], dc[3];
     {
@@ -500,19 +526,29 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
         return fn ? co : sn;
     };
     f32x16 P[8], C[8];
+    u32x4 mk = {0u, 0u, 0u, 0u};
     const auto relu_val = [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
-        return fmaxf(P[b][4 * q + i], 0.f);
+        const float z = P[b][4 * q + i];
+        if (SAVE) mask_set(mk, b, 4 * q + i, z > 0.f);
+        return fmaxf(z, 0.f);
     };
+    const size_t mrow = pl * 2 + hi;
+    const size_t hstride = (size_t)Mp * 256;
+    float* Hrow = CH + pl * 256 + 4 * hi;                     // + (l - 1) Mp 256: h_l of this lane's point
+    float* Irow = CIN + pl * 128 + 4 * hi;
     init8(C, biasL, hi);
-    gemm_r<6>(C, ws, small_val, side);
+    gemm_rs<6>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Irow, s, v); });
     kb = ws.k;
     gemm_r<16, 2, true>(C, ws, feat_val, side);
     copy8(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
-        gemm_r<16>(C, ws, relu_val, side);
+        float* Hl = Hrow + (size_t)(l - 1) * hstride;
+        mk = u32x4{0u, 0u, 0u, 0u};
+        gemm_rs<16>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Hl, s, v); });
+        if (SAVE) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
         if (l == 4) {       // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
             gemm_r<6>(C, ws, small_val, side);
             kb = ws.k;
@@ -522,14 +558,24 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     }
     {
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        mk = u32x4{0u, 0u, 0u, 0u};
+        float* H8 = Hrow + (size_t)7 * hstride;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
-                const float h = fmaxf(P[b][r], 0.f);
-                d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
+            for (int q = 0; q < 4; ++q) {
+                float h4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i, f = 32 * b + 8 * q + 4 * hi + i;
+                    const float h = fmaxf(P[b][r], 0.f);
+                    if (SAVE) mask_set(mk, b, r, P[b][r] > 0.f);
+                    h4[i] = h;
+                    d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);
+                }
+                if (SAVE) st4(H8 + 32 * b + 8 * q, h4[0], h4[1], h4[2], h4[3]);
             }
+        if (SAVE) masks[((size_t)7 * Mp) * 2 + mrow] = mk;
         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
         if (hi == 0 && live) {
             float* o = ws_rgb + (size_t)point * 3;
@@ -544,33 +590,48 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
 static int infer_attrs() {
     static DeviceOnce attr_done;
     if (attr_done.first()) {
-        if (int e = allow_big_lds(k_deform_jvp_x3r, XI_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_deform_vjp_x3r, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_jvp_x3r<false>, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_jvp_x3r<true>, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_vjp_x3r<false>, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_vjp_x3r<true>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_color_fwd_x3r<true>, XC_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_color_fwd_x3r<false>, XC_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<true, false>, XC_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<false, false>, XC_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<true, true>, XC_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_color_fwd_x3r<false, true>, XC_LDS_BYTES)) return e;
         attr_done.done();
     }
     return ST_OK;
 }
 // packed_r = the k-step-ordered split weights of pack_x3r (query_x3r.hip)
-int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st) {
+// save: the workspace was laid out with PF_SAVE and the kernel keeps what the weight-gradient GEMMs need (training)
+int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
     ScopedTimer tm(KID_DEFORM_FWD_X3, src.M, st);
-    hipLaunchKernelGGL(k_deform_jvp_x3r, dim3(L.Mp / 64), dim3(XR_THREADS), XI_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
-                       ws + L.off[WS_XC], ws + L.off[WS_V], reinterpret_cast<u32x4*>(ws + L.off[WS_D_MASK]), L.Mp);
+    const dim3 grid(L.Mp / 64), block(XR_THREADS);
+    const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
+    u32x4* mk = reinterpret_cast<u32x4*>(ws + L.off[WS_D_MASK]);
+    if (save) hipLaunchKernelGGL(k_deform_jvp_x3r<true>, grid, block, XI_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], mk,
+                                 ws + L.off[WS_D_U0], ws + L.off[WS_D_U], L.Mp);
+    else hipLaunchKernelGGL(k_deform_jvp_x3r<false>, grid, block, XI_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], mk,
+                            (float*)nullptr, (float*)nullptr, L.Mp);
     return hip_last("deform_jvp_x3r");
 }
-int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st) {
+int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
     ScopedTimer tm(KID_DEFORM_VJP_X3, src.M, st);
-    hipLaunchKernelGGL(k_deform_vjp_x3r, dim3((L.Mp + 127) / 128), dim3(XR_THREADS), XI_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
-                       ws + L.off[WS_GC], ws + L.off[WS_GO], reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]), L.Mp);
+    const dim3 grid((L.Mp + 127) / 128), block(XR_THREADS);
+    const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
+    const u32x4* mk = reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]);
+    if (save) hipLaunchKernelGGL(k_deform_vjp_x3r<true>, grid, block, XI_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_GC], ws + L.off[WS_GO], mk,
+                                 ws + L.off[WS_D_R], L.Mp);
+    else hipLaunchKernelGGL(k_deform_vjp_x3r<false>, grid, block, XI_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_GC], ws + L.off[WS_GO], mk,
+                            (float*)nullptr, L.Mp);
     return hip_last("deform_vjp_x3r");
 }
 
@@ -590,18 +651,20 @@ int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, fl
     return hip_last("sdf_fwd_x3r");
 }
 
-// colour of the points [0, Mcp)
-int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, hipStream_t st) {
+// colour of the points [0, Mcp); save (training): whole 128-point blocks, + WS_C_IN / WS_C_H / WS_C_MASK
+int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, bool save, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     if (Mcp <= 0) return ST_OK;
     const Tabs tb = make_tabs();
     ScopedTimer tm(KID_COLOR_FWD_X3, Mcp, st);
     const dim3 grid((Mcp + 127) / 128), block(XR_THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
-    if (deform) hipLaunchKernelGGL(k_color_fwd_x3r<true>, grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], ws + L.off[WS_GC],
-                                   ws + L.off[WS_FEAT], ws + L.off[WS_RGB], Mcp);
-    else hipLaunchKernelGGL(k_color_fwd_x3r<false>, grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], ws + L.off[WS_V], ws + L.off[WS_GC],
-                            ws + L.off[WS_FEAT], ws + L.off[WS_RGB], Mcp);
+    float* cin = ws + L.off[WS_C_IN]; float* ch = ws + L.off[WS_C_H]; u32x4* mk = reinterpret_cast<u32x4*>(ws + L.off[WS_C_MASK]);
+#define ES_LAUNCH_COLOR_X3R(D, S) hipLaunchKernelGGL((k_color_fwd_x3r<D, S>), grid, block, XC_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_XC], \
+        ws + L.off[WS_V], ws + L.off[WS_GC], ws + L.off[WS_FEAT], ws + L.off[WS_RGB], cin, ch, mk, Mcp, L.Mp)
+    if (deform) { if (save) ES_LAUNCH_COLOR_X3R(true, true); else ES_LAUNCH_COLOR_X3R(true, false); }
+    else { if (save) ES_LAUNCH_COLOR_X3R(false, true); else ES_LAUNCH_COLOR_X3R(false, false); }
+#undef ES_LAUNCH_COLOR_X3R
     return hip_last("color_fwd_x3r");
 }
 

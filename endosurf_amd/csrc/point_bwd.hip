@@ -626,8 +626,15 @@ static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
     return ST_OK;
 }
 
+// train_x3r.hip / query_x3.hip
+int deform_tan_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, const float* d_go, hipStream_t st);
+int color_bwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int m_color, const float* d_rgb,
+                  hipStream_t st);
+int deform_bwd_x3r(const void* packed_r, const float* weff, float* ws, const WsLayout& L, int M, int m_color, hipStream_t st);
+const void* packed_x3r_part(const void* packed_x3);
+
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
-                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st) {
+                          const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st, const void* packed_x3) {
     if (src.M <= 0) return ST_OK;
     BwdArgs a;
     a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
@@ -635,6 +642,17 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
     const int Mp = a.L.Mp, Mcp = round_up64(a.M_color);
     const bool deform = flags & PF_DEFORM;
+    if (flags & PF_X3_CHAIN) {
+        // the workspace comes from the split-precision training chain (point_fwd.hip): the deformation family's backward on the
+        // register-resident core (train_x3r.hip), SDF and colour networks on the fp32 kernels
+        if (!packed_x3) return fail(ST_BAD_ARG, "point_backward_chains", "PF_X3_CHAIN needs the split weights (es_pack_x3)");
+        const void* pr = packed_x3r_part(packed_x3);
+        if (flags & PF_COLOR) { if (int e = color_bwd_x3r(src, pr, weff, ws, a.L, deform, a.M_color, d_rgb, st)) return e; }
+        if (deform) { if (int e = deform_tan_x3r(src, pr, weff, ws, a.L, d_go, st)) return e; }
+        { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        if (deform) { if (int e = deform_bwd_x3r(pr, weff, ws, a.L, src.M, a.M_color, st)) return e; }
+        return hip_last("point_backward_chains");
+    }
     if (deform && aux_tail(flags, a.M_color, src.M)) {
         // tail stages mixed into the main launches as in point_fwd.hip:
         //   colour_bwd(main) | tan(main) | sdf_bwd(main) | [tan + sdf_bwd](tail) + deform_bwd(main) | deform_bwd(tail)

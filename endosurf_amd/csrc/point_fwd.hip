@@ -425,7 +425,7 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
             const float* v = wsb(a, WS_V) + gp * 3;      // d_c = J d / (|J d| + 1e-10)   endosurf.py:684-685
             v0 = v[0]; v1 = v[1]; v2 = v[2];
         }
-        const float inv = 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
+        const float inv = (a.flags & PF_RAW_DIR) ? 1.f : 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
         pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
     }
     __syncthreads();
@@ -543,10 +543,10 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 
 // -------------------------------------------------------------------------------------------------------------
 // infer_x3r.hip / query_x3.hip
-int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
-int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, hipStream_t st);
+int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
+int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
 int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st);
-int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, hipStream_t st);
+int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, bool save, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
 // packed_x3 (nullable): the split weights of es_pack_x3; with PF_X3 and without PF_SAVE the deformation- and SDF-network launches of a
@@ -563,10 +563,19 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     if ((flags & PF_X3) && !(flags & PF_SAVE) && packed_x3) {
         // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour | VJP
         const void* pr = packed_x3r_part(packed_x3);
-        if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, st)) return e; }
+        if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, false, st)) return e; }
         if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, st)) return e;
-        if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, st)) return e; }
-        return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, st) : hip_last("point_forward");
+        if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, false, st)) return e; }
+        return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, false, st) : hip_last("point_forward");
+    }
+    if ((flags & PF_X3_CHAIN) && (flags & PF_SAVE) && packed_x3) {
+        // opt-in split-precision TRAINING chain: the deformation family runs on the register-resident core and keeps what the backward
+        // needs in the fp32 kernels' layouts (masks excepted: PF_X3_CHAIN tells the backward); SDF and colour networks: fp32 kernels
+        const void* pr = packed_x3r_part(packed_x3);
+        if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, true, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, true, st)) return e; }
+        return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, true, st) : hip_last("point_forward");
     }
     if (deform && aux_tail(flags, a.M_color, src.M)) {
         // main tiles [0, Mc), colour-less tail [Mc, Mp).  Every main launch is a whole number of rounds of the 512 workgroup
@@ -596,6 +605,22 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
     if (flags & PF_COLOR) { ScopedTimer tm(KID_COLOR_FWD, a.M_color, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mcp / TM, 0, st)) return e; }
     if (deform) { ScopedTimer tm(KID_DEFORM_VJP, src.M, st); if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, Mp / TM, 0, st)) return e; }
     return hip_last("point_forward");
+}
+
+
+// ColorNetwork.forward(x, n, d, geo_feat) (reference endosurf.py:828-842) on explicit inputs: the caller has written x -> WS_XC,
+// n -> WS_GC, geo_feat -> WS_FEAT of a (PF_COLOR, no deformation) workspace and passes d as the point source's view directions; only
+// the colour body runs, with the direction taken as given (EndoSurfNet.forward normalises J d before it calls the colour network,
+// the colour network itself does not).  rgb -> WS_RGB.
+int color_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, hipStream_t st) {
+    if (src.M <= 0) return ST_OK;
+    FwdArgs a;
+    a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
+    a.flags = PF_COLOR | PF_RAW_DIR;
+    a.L = ws_layout(src.M, PF_COLOR); a.M_color = src.M;
+    ScopedTimer tm(KID_COLOR_FWD, src.M, st);
+    if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, a.L.Mp / TM, 0, st)) return e;
+    return hip_last("color_forward");
 }
 
 }  // namespace es

@@ -63,7 +63,8 @@ const char* es_kernel_name(int kid) {
     static const char* names[KID_COUNT] = {"k_query_sdf", "k_deform_fwd", "k_sdf_fwd", "k_color_fwd", "k_color_bwd", "k_sdf_bwd",
                                            "k_deform_bwd", "k_wgrad[deform]", "k_wgrad[sdf]", "k_wgrad[color]", "k_wgrad_small",
                                            "k_query_sdf[later marching blocks: tiles of finished rays exit]", "k_deform_vjp", "k_deform_tan", "k_query_sdf16", "k_query_sdf_x3", "k_wgrad_x3[deform]", "k_wgrad_x3[sdf]", "k_wgrad_x3[color]",
-                                           "k_deform_fwd_x3", "k_sdf_fwd_x3", "k_color_fwd_x3", "k_deform_vjp_x3"};
+                                           "k_deform_fwd_x3", "k_sdf_fwd_x3", "k_color_fwd_x3", "k_deform_vjp_x3",
+                                           "k_deform_tan_x3", "k_deform_bwd_x3", "k_color_bwd_x3", "k_sdf_bwd_x3"};
     return kid >= 0 && kid < KID_COUNT ? names[kid] : "?";
 }
 

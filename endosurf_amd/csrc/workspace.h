@@ -1,6 +1,7 @@
 // Layout of the per-call point-evaluation workspace (one caller-owned fp32 device buffer).
 //
-// All per-point tensors are row-major [Mp][ld] with Mp = M rounded up to a multiple of 64 so that tiles never
+// All per-point tensors are row-major [Mp][ld] with Mp = M rounded up to a multiple of 128 (two 64-row tiles of the fp32 kernels = one
+// 128-point block of the register-resident split-precision kernels) so that tiles never
 // need row guards; rows >= M carry finite junk in forward buffers and exact zeros in every adjoint buffer.
 // The four [8][Mp][256] stacks of the SDF kernels (WS_S_ACT, WS_S_RHO, WS_S_TAU, WS_S_ZB) are NOT row-major: each [64 x 256] tile
 // is stored in accumulator-fragment order (chain_common.h frag_off) because the SDF epilogues load and store them per quad.
@@ -16,6 +17,9 @@ namespace es {
 constexpr int PF_DEFORM = 1;   // deformation network present (use_deform)
 constexpr int PF_COLOR = 2;    // evaluate the colour network (render_core) — off for errorondepth / surface_neighbour_error
 constexpr int PF_SAVE = 4;     // keep activations for the backward pass (training)
+constexpr int PF_X3_CHAIN = 32; // OPT-IN: the workspace belongs to the split-precision TRAINING chain (infer_x3r.hip with SAVE / train_x3r.hip): its
+                                // ReLU mask words are in that family's layout, so the backward must run that family's kernels.  No effect on offsets
+constexpr int PF_RAW_DIR = 16;  // colour-only evaluation on explicit inputs (es_color_forward): the view direction is used as given, not normalised
 constexpr int PF_X3 = 8;       // OPT-IN: weight-gradient GEMMs in split precision (3 x bf16 planes, wgrad.hip); no effect on layouts
 
 enum WsBuf : int {
@@ -59,10 +63,11 @@ struct WsLayout {
 };
 
 inline int round_up64(int m) { return (m + 63) / 64 * 64; }
+inline int round_up_rows(int m) { return (m + 127) / 128 * 128; }      // rows of every workspace buffer
 
 inline WsLayout ws_layout(int M, int flags) {
     WsLayout L;
-    const size_t Mp = (size_t)round_up64(M);
+    const size_t Mp = (size_t)round_up_rows(M);
     L.Mp = (int)Mp;
     const bool def = flags & PF_DEFORM, col = flags & PF_COLOR, save = flags & PF_SAVE;
     size_t sz[WS_COUNT] = {0};

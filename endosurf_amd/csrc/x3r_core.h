@@ -12,7 +12,11 @@ namespace es {
 constexpr int XR_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2, SF3, SF4M, SF4A, SF5, SF6, SF7,
                            DR7, DR6, DR5, DR4, DR3, DR2, DR1, DR0,
                            SF8F, SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0,
-                           CF0S, CF0F, CF1, CF2, CF3, CF4H, CF4S, CF4F, CF5, CF6, CF7};
+                           CF0S, CF0F, CF1, CF2, CF3, CF4H, CF4S, CF4F, CF5, CF6, CF7,
+                           // [46, 57) colour reverse sweep (train_x3r.hip): the three parts of the skip layer's input adjoint read the same operand
+                           CR7, CR6, CR5, CR4F, CR4S, CR4H, CR3, CR2, CR1, CR0F, CR0S,
+                           // [57] feature rows of the SDF network's last layer, reverse (seed of the SDF backward's reverse sweep)
+                           SR8F};
 constexpr int XR_COUNT = sizeof(XR_SEGS) / sizeof(int);
 constexpr int xr_kg(int i) { return 2 * cdiv(SEGS[XR_SEGS[i]].kreal, 32); }      // k-steps, even (the stream works in pairs)
 constexpr int xr_chunk0(int i) {
@@ -27,6 +31,8 @@ constexpr int XR_QUERY_CHUNKS = xr_chunk0(17);            // 236: end of the que
 constexpr int XR_DR_CHUNK0 = xr_chunk0(17);               // first k-step of DR7
 constexpr int XR_SI_CHUNK0 = xr_chunk0(25);               // first k-step of SF8F (then SR7 ...)
 constexpr int XR_C_CHUNK0 = xr_chunk0(35);                // first k-step of CF0S
+constexpr int XR_CR_CHUNK0 = xr_chunk0(46);               // first k-step of CR7
+constexpr int XR_SR8F_CHUNK0 = xr_chunk0(57);             // first k-step of SR8F
 constexpr int XR_SDF_FWD_CHUNKS = XR_QUERY_CHUNKS - XR_SDF_CHUNK0;      // 120 k-steps of SF0 .. SF7
 constexpr int XR_CHUNK_UNITS = 8 * 3;                     // 1 KB units (64 lanes x 16 B) per k-step
 constexpr int XR_CHUNK_BYTES = XR_CHUNK_UNITS * 1024;
@@ -34,6 +40,7 @@ constexpr int XR_THREADS = 256;
 constexpr int XR_ENC_LD = 68;                             // floats per column row of the encoding scratch (conflict-free b32 / b128 reads)
 constexpr int XR_RING = 4;                                // k-steps resident in LDS
 static_assert(XR_SDF_CHUNK0 % 2 == 0 && XR_DR_CHUNK0 % 2 == 0 && XR_SI_CHUNK0 % 2 == 0 && XR_C_CHUNK0 % 2 == 0 && XR_CHUNKS % 2 == 0, "k-step pairs");
+static_assert(XR_SEGS[46] == CR7 && XR_SEGS[56] == CR0S && XR_SEGS[57] == SR8F && XR_COUNT == 58, "segment order the training kernels hard-code");
 static_assert(LAYER_N[NET_D][3] == 204 && LAYER_N[NET_S][7] == 256 && SEGS[SF4A].kreal == 39, "shapes the kernels hard-code");
 
 // position j (0..7) of lane half hi in k-step-local order -> k offset inside the 16-wide step
@@ -97,14 +104,20 @@ extern __device__ long long xr_prof[512];
 #endif
 
 struct FragB { u32x4 h, m, l; };
-template <class VAL>
-__device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s) {
+// SINK: sink(s, v) receives the 8 fp32 operand elements of k-step s (element j <-> k offset xr_kperm(hi, j)) once, right after they
+// were built -- the training kernels stream them out as the saved layer inputs / adjoints of the weight-gradient GEMMs
+struct NoSink { __device__ __forceinline__ void operator()(int, const float (&)[8]) const {} };
+template <class VAL, class SINK>
+__device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s, SINK&& sink) {
+    float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned hh, mm, ll;
-        split_pair(val(s, 2 * j), val(s, 2 * j + 1), hh, mm, ll);
+        v[2 * j] = val(s, 2 * j); v[2 * j + 1] = val(s, 2 * j + 1);
+        split_pair(v[2 * j], v[2 * j + 1], hh, mm, ll);
         b.h[j] = hh; b.m[j] = mm; b.l[j] = ll;
     }
+    sink(s, v);
 }
 
 // C[fb] += W[32 fb .. +31][k-steps 0 .. KG) . B, with B's k-step s operand = split(val(s, 0..7)); the operand of k-step s+1 is built
@@ -157,8 +170,8 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
 #endif
     }
 }
-template <int NG, bool LATE, bool ODD, class VAL, class SIDE>
-__device__ __forceinline__ void kstep_r(f32x16 (&C)[8], WStream& ws, FragB& b, VAL&& val, SIDE&& side, int snext, bool more) {
+template <int NG, bool LATE, bool ODD, class VAL, class SIDE, class SINK>
+__device__ __forceinline__ void kstep_r(f32x16 (&C)[8], WStream& ws, FragB& b, VAL&& val, SIDE&& side, SINK&& sink, int snext, bool more) {
     FragB nb = b;
     float v[8];
     FragA a1;
@@ -167,23 +180,26 @@ __device__ __forceinline__ void kstep_r(f32x16 (&C)[8], WStream& ws, FragB& b, V
     if (ODD) ws.landed_barrier();
     ws.read_group(ws.a0, ws.k + 1, 0);
     mfma_group<1, NG == 2, LATE && ODD, !ODD>(C, ws, a1, b, nb, v, val, snext, more, side);
+    if (more) sink(snext, v);
     b = nb;
     ++ws.k;
 }
 // NG = 1: only accumulator group 0 (features 0 .. 127) is computed -- the stream, its barriers and the operand build are unchanged.
 // LATE: val(s, .) of an EVEN k-step s reads data that lands with the barrier inside k-step s - 1 (a side stream): those operands are
 // built after that barrier.
-template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE>
-__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side) {
+template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE, class SINK>
+__device__ __forceinline__ void gemm_rs(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side, SINK&& sink) {
     static_assert(KG % 2 == 0, "k-step pairs");
     FragB b;
-    build_frag(b, val, 0);
+    build_frag(b, val, 0, sink);
 #pragma unroll
     for (int sp = 0; sp < KG / 2; ++sp) {
-        kstep_r<NG, LATE, false>(C, ws, b, val, side, 2 * sp + 1, true);
-        kstep_r<NG, LATE, true>(C, ws, b, val, side, 2 * sp + 2, 2 * sp + 2 < KG);
+        kstep_r<NG, LATE, false>(C, ws, b, val, side, sink, 2 * sp + 1, true);
+        kstep_r<NG, LATE, true>(C, ws, b, val, side, sink, 2 * sp + 2, 2 * sp + 2 < KG);
     }
 }
+template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE>
+__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side) { gemm_rs<KG, NG, LATE>(C, ws, val, side, NoSink()); }
 template <int KG, int NG = 2, class VAL>
 __device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) { gemm_r<KG, NG, false>(C, ws, val, NoSide()); }
 
@@ -200,6 +216,27 @@ __device__ __forceinline__ void init8(f32x16 (&C)[8], const float* bl, int hi) {
 __device__ __forceinline__ void copy8(f32x16 (&P)[8], const f32x16 (&C)[8]) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) P[b] = C[b];
+}
+
+// four consecutive features of one row of a row-major [rows][256] stack (streamed once: non-temporal)
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+    const v4f_frag t = {a, b, c, d};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_frag*>(p));
+}
+// the operand of k-step s (8 values: features 16 s + 4 hi .. + 3 and 16 s + 8 + 4 hi .. + 3) into a row whose base already holds + 4 hi
+__device__ __forceinline__ void st_kstep(float* row_hi, int s, const float (&v)[8]) {
+    st4(row_hi + 16 * s, v[0], v[1], v[2], v[3]);
+    st4(row_hi + 16 * s + 8, v[4], v[5], v[6], v[7]);
+}
+
+// mask bit of register r of feature block b inside the 128-bit word of a (layer, point, lane half)
+__device__ __forceinline__ void mask_set(u32x4& mk, int b, int r, bool m) { mk[b >> 1] |= (m ? 1u : 0u) << ((b & 1) * 16 + r); }
+__device__ __forceinline__ bool mask_get(const u32x4& mk, int b, int r) { return (mk[b >> 1] >> ((b & 1) * 16 + r)) & 1u; }
+
+// the element of the VALUE column of this lane's point: lanes 0-15 of a lane half keep their own, lanes 16-31 get their partner's
+// (v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first operand with the even rows of its second)
+__device__ __forceinline__ float value_row(float z) {
+    return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false)[0]);
 }
 
 }  // namespace es

@@ -47,6 +47,9 @@ class Engine:
         self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
         self._x3 = None
         self.x3_infer_min = 16384      # points: below this a launch of 64/128-point tiles does not fill the chip
+        # split-precision mode: grad-enabled evaluations run the split-precision TRAINING chain (infer_x3r.hip with saves +
+        # train_x3r.hip); False keeps the fp32 chain kernels under the split-precision queries / weight gradients (round-2 behaviour)
+        self.x3_train_chain = os.environ.get("ES_X3_TRAIN", "1") not in ("0", "", "false", "False")
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -317,7 +320,8 @@ class PointCtx:
 
     def __init__(self, eng: "Engine", pts, flags: int, m_color: int = 0):
         self.eng, self.pts, self.flags, self.M, self.m_color = eng, pts, flags, pts.M, int(m_color)
-        self.Mp = (self.M + 63) // 64 * 64
+        self.x3_chain, self.px3 = False, None      # set by Engine.point_forward when the split-precision training chain produced it
+        self.Mp = (self.M + 127) // 128 * 128        # csrc/workspace.h round_up_rows
         n = int(eng.lib.es_point_workspace_floats(self.M, flags))
         self.ws = eng.empty(max(n, 1))
 
@@ -331,11 +335,15 @@ class PointCtx:
 def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, like_save: bool = False) -> PointCtx:
     """``like_save``: evaluate with the kernels a PF_SAVE call would run (the forward pass of a chunked, re-evaluated render)."""
     ctx = PointCtx(self, pts, flags, m_color)
-    if self.split_precision and not (flags & _lib.PF_SAVE) and not like_save and pts.M >= self.x3_infer_min:
-        # opt-in: the deformation- and SDF-network launches of a large no-grad evaluation in split precision (csrc/infer_x3r.hip)
+    save = bool(flags & _lib.PF_SAVE)
+    if self.split_precision and not like_save and pts.M >= self.x3_infer_min and (self.x3_train_chain or not save):
+        # opt-in: the launches of a large evaluation in split precision -- csrc/infer_x3r.hip without PF_SAVE; with PF_SAVE the
+        # split-precision TRAINING chain, whose workspace must go through es_point_backward_x3 (``ctx.x3_chain``)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
         check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(px3), ptr(weff), ptr(ctx.ws), flags, int(m_color),
                                            self.st()), "es_point_forward_x3")
+        ctx.x3_chain = save
+        ctx.px3 = px3
     else:
         check(self.lib.es_point_forward(C.byref(pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, int(m_color), self.st()), "es_point_forward")
     return ctx
@@ -357,6 +365,11 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, 
         assert d_rgb.shape[0] == mc
     if dweff is None:
         dweff = self.zeros(self.n_weff)
+    if ctx.x3_chain:      # the workspace of the split-precision training chain: that family's backward kernels
+        check(self.lib.es_point_backward_x3(C.byref(ctx.pts), ptr(packed), ptr(ctx.px3), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf),
+                                            ptr(d_go), ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()),
+              "es_point_backward_x3")
+        return dweff
     flags = ctx.flags | (_lib.PF_X3 if self.split_precision else 0)      # opt-in: weight-gradient GEMMs in split precision
     check(self.lib.es_point_backward_det(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
                                          ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()), "es_point_backward")

@@ -122,9 +122,27 @@ class SDFNetwork(_MLP):
 
 class ColorNetwork(_MLP):
     def forward(self, x, n, d, geo_feat):
-        raise NotImplementedError(
-            "the colour MLP is evaluated only inside the fused chain (x_c, g_c, d_c and the features never leave the chip); use "
-            "EndoSurfNet.forward / EndoSurfRenderer.renderonpts for colours at given points")
+        """sigmoid rgb [M,3] of the colour MLP on EXPLICIT inputs (reference ColorNetwork.forward, endosurf.py:828-842): position x
+        (encoded with L = 10), normal n (used as given), view direction d (encoded with L = 4, used as given: EndoSurfNet.forward
+        normalises J d before this call, :684-685) and the 256 geometry features.  One launch of the fused chain's colour body on a
+        workspace whose x_c / g_c / feature buffers hold the inputs (es_color_forward).  No grad, like the other per-network forwards."""
+        m, r = self._ctx()
+        with torch.cuda.device(r.device), torch.no_grad():
+            f = lambda a, w: a.detach().to(device=r.device, dtype=torch.float32).reshape(-1, w).contiguous()
+            x, n, d, feat = f(x, 3), f(n, 3), f(d, 3), f(geo_feat, 256)
+            M = x.shape[0]
+            if not (n.shape[0] == d.shape[0] == feat.shape[0] == M):
+                raise ValueError("x, n, d and geo_feat must hold one row per point")
+            if M == 0:
+                return torch.zeros(0, 3, device=r.device)
+            weff, packed = r._weights()
+            eng = r.engine
+            pts = eng.points(x=x, t=torch.zeros(1, device=r.device), dirs=d)
+            pctx = PointCtx(eng, pts, _lib.PF_COLOR)
+            pctx.view("xc").copy_(x); pctx.view("gc").copy_(n); pctx.view("feat").copy_(feat)
+            _lib.check(eng.lib.es_color_forward(_lib.C.byref(pts), _lib.ptr(packed), _lib.ptr(weff.detach()), _lib.ptr(pctx.ws), eng.st()),
+                       "es_color_forward")
+            return pctx.view("rgb").clone()
 
 
 class SingleVarianceNetwork(nn.Module):

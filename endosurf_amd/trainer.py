@@ -56,6 +56,8 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     eod_pts = aux_x[:N]
     main.wait_stream(side)
     z.record_stream(main)
+    # (the split-precision training chain takes the auxiliary points in the same launches as well; evaluating them with the fp32
+    # kernels on the side stream instead was measured and is no faster: a co-running launch breaks the whole-round fit of the main ones)
     ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
     a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
     if loss_kernel:

@@ -127,6 +127,7 @@ torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)
 assert dist.get_backend() == "nccl"
 def run(dp):
+    torch.manual_seed(0)                     # the stratified jitter / neighbour offsets are drawn with torch.rand on the device
     r = renderer_for(5, "trained", True)
     r.engine.deterministic = True
     tr = Trainer(r, lr=1e-3, data_parallel=dp, force_collective=dp)

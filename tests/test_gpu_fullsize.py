@@ -137,3 +137,29 @@ def test_config3_2048_rays_128_samples_eikonal_and_step():
     before = r4.model._flat.clone()
     loss4, _, _ = tr4.train_step(_scene(16), 60000)
     assert np.isfinite(float(loss4)) and float((r4.model._flat - before).abs().max()) > 1e-5
+
+
+def test_config5_full_frame_chunks_equal_direct_forwards():
+    """BASELINE config 5 at full size: one 640 x 512 frame (327 680 rays) through render_frames' hipGraph-replayed 2048-ray chunks.
+    The first, a middle and the LAST chunk of the frame are compared with a direct forward of the same 2048 rays (same launch shapes
+    => bit-identical), the frame is finite and inside the compositing bounds, and an odd frame size (tail chunk) covers every ray."""
+    from endosurf_amd.trainer import SyntheticScene
+    r = renderer_for(202, "trained", True)
+    sc = SyntheticScene("cuda", seed=3)
+    rays = sc.frame(H=512, W=640, t=0.5)
+    C = 2048
+    out = r.render_frames(rays, iter_step=1, ray_chunk=C, perturb_overwrite=False, use_graph=True)
+    flat = rays.reshape(-1, 9)
+    n = flat.shape[0]
+    assert n == 327680 and out["color"].shape == (n, 3) and out["depth"].shape == (n, 1) and out["normal"].shape == (n, 3)
+    for k in ("color", "depth", "normal"):
+        assert bool(torch.isfinite(out[k]).all()), k
+    assert float(out["color"].min()) >= 0.0 and float(out["color"].max()) <= 1.0 + 1e-5
+    for i0 in (0, (n // C // 2) * C, n - C):
+        with torch.no_grad():
+            ret = r(flat[i0:i0 + C], iter_step=1, perturb_overwrite=False)
+        normal = (ret["gradients_o"] * ret["weights"][:, :, None]).sum(1)
+        for k, ref in (("color", ret["color_map"]), ("depth", ret["depth_map"]), ("normal", normal)):
+            assert torch.equal(out[k][i0:i0 + C], ref), (k, i0, float((out[k][i0:i0 + C] - ref).abs().max()))
+    # the frame is not flat: the chunks differ from each other (a stuck static input buffer would repeat one chunk)
+    assert float((out["color"][:C] - out["color"][n - C:]).abs().max()) > 1e-3

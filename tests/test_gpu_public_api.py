@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import renderer_for_case
+from gpu_util import renderer_for, renderer_for_case
 from oracle_util import CASES, load_case
 
 pytestmark = pytest.mark.gpu
@@ -163,7 +163,7 @@ def test_surface_neighbour_error_documented_divergences():
 @pytest.mark.parametrize("name", CASES)
 def test_sub_network_forwards(name):
     """renderer.model.{deform_network(x, t), sdf_network(x_c), sdf_network.sdf(x_c), deviation_network(x)} (endosurf.py:724-852)
-    against the reference's pt64/* vectors; the colour network alone is refused with an explanation."""
+    against the reference's pt64/* vectors."""
     c = load_case(name)
     r = renderer_for_case(c)
     m = r.model
@@ -181,5 +181,24 @@ def test_sub_network_forwards(name):
     inv_s = m.deviation_network(x)
     assert tuple(inv_s.shape) == (x.shape[0], 1) and inv_s.requires_grad
     assert abs(float(inv_s[0, 0]) - float(np.exp(10.0 * float(m.deviation_network.variance)))) < 1e-3
-    with pytest.raises(NotImplementedError):
-        m.color_network(x_c, x_c, x_c, torch.zeros(x.shape[0], 256, device="cuda"))
+    # the colour network on explicit inputs: test_color_network_forward_on_explicit_inputs below
+
+
+@pytest.mark.parametrize("name", ["trained_deform", "init_deform"])
+def test_color_network_forward_on_explicit_inputs(name):
+    """renderer.model.color_network(x, n, d, geo_feat) = the reference's ColorNetwork.forward on explicit inputs (endosurf.py:828-842):
+    d is taken as given (NOT normalised), M is not a multiple of the tile.  Budget: 3x the reference's own fp32-vs-fp64 error."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "color_direct.npz"))
+    seed, trained, use_deform = (int(v) for v in g[f"{name}/meta"])
+    r = renderer_for(seed, "trained" if trained else "init", bool(use_deform))
+    x, n, d, feat = (torch.from_numpy(g[f"{name}/{k}"]).cuda() for k in ("x", "n", "d", "feat"))
+    rgb = r.model.color_network(x, n, d, feat)
+    assert tuple(rgb.shape) == (x.shape[0], 3)
+    ref64 = g[f"{name}/rgb64"]
+    budget = 3 * float(np.abs(g[f"{name}/rgb"].astype(np.float64) - ref64).max()) + 2e-6
+    assert float(np.abs(rgb.double().cpu().numpy() - ref64).max()) <= budget
+    # a scaled direction gives a different colour (the network does not normalise it) and the leading shape is free
+    rgb2 = r.model.color_network(x.reshape(4, 50, 3), n.reshape(4, 50, 3), 2.0 * d.reshape(4, 50, 3), feat.reshape(4, 50, 256))
+    assert tuple(rgb2.shape) == (200, 3) and float((rgb2 - rgb).abs().max()) > 1e-4
+    assert r.model.color_network(x[:0], n[:0], d[:0], feat[:0]).shape == (0, 3)

@@ -176,7 +176,11 @@ def test_bench_work_model_and_self_launch(monkeypatch):
     D, S, C = bench.MAC_D, bench.MAC_S, bench.MAC_C
     assert a2["upsample"] * 1e9 == pytest.approx(2 * 56 * (D + S)) and a2["render_core_forward"] * 1e9 == pytest.approx(2 * 64 * (3 * D + 2 * S + C))
     assert a4["render_core_forward"] * 1e9 == pytest.approx(2 * 64 * (2 * S + C))          # no deformation network
-    assert bench.kernel_macs("k_query_sdf", False) == S and bench.kernel_macs("k_wgrad[deform]", True) == 3 * D
+    assert bench.kernel_macs("k_query_sdf", False, executed=False) == S and bench.kernel_macs("k_wgrad[deform]", True) == 3 * D
+    # executed work: a query issues only the sdf row of the [257 x 256] last layer; the SDF chain kernels skip it in one of their sweeps
+    assert bench.kernel_macs("k_query_sdf", True) == D + S - 65536 and bench.kernel_macs("k_query_sdf_x3", True) == D + S - 65536
+    assert bench.kernel_macs("k_sdf_fwd", True) == 2 * S - 65536 and bench.kernel_macs("k_sdf_bwd", True) == 2 * S - 65792
+    assert bench.kernel_macs("k_wgrad_x3[sdf]", True) == 2 * S - 65536 and bench.kernel_macs("k_color_fwd", True, executed=False) == C
     assert bench.kernel_macs("k_query_sdf[later marching blocks: tiles of finished rays exit]", True) is None      # never counted as work
     assert bench.render_cfg(bench.CONFIGS[3])["n_samples"] == 64 and bench.CONFIGS[3]["rays"] == 2048
     # `python bench.py --gpus 4` without a launcher in the environment re-executes itself under torch.distributed.run

@@ -184,3 +184,18 @@ def test_fp64_forward_tight(name):
     assert np.array_equal(np.isinf(d_i.numpy()), np.isinf(ref))
     fin = np.isfinite(ref)
     assert maxdiff(d_i.numpy()[fin], ref[fin]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["trained_deform", "init_deform"])
+def test_color_network_on_explicit_inputs(name):
+    """OracleNet.color vs ColorNetwork.forward(x, n, d, geo_feat) of the reference (tests/golden/color_direct.npz, tools/make_golden_color.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "color_direct.npz"))
+    seed, trained, use_deform = (int(v) for v in g[f"{name}/meta"])
+    import weightgen
+    from oracle import endosurf_oracle as O
+    state = weightgen.make_state(seed, "trained" if trained else "init", bool(use_deform))
+    for dtype, key, tol in ((torch.float64, "rgb64", 1e-9), (torch.float32, "rgb", 2e-5)):
+        net = O.OracleNet({k: torch.tensor(v, dtype=dtype) for k, v in state.items()}, bool(use_deform))
+        rgb = net.color(*(torch.tensor(g[f"{name}/{k}"], dtype=dtype) for k in ("x", "n", "d", "feat")))
+        assert float((rgb.double() - torch.tensor(g[f"{name}/{key}"], dtype=torch.float64)).abs().max()) < tol

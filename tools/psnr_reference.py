@@ -31,6 +31,10 @@ n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dtype = getattr(torch, sys.argv[3]) if len(sys.argv) > 3 else torch.float32
 threads = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 out_name = sys.argv[5] if len(sys.argv) > 5 else "psnr_reference"
+# low-chaos variant (round 3): the same schedule with the learning rate scaled down (PSNR_LR_SCALE=0.25, 600 iterations): runs of the
+# reference that differ only in the summation order then stay close to each other, which allows a TIGHT plateau comparison
+LR_SCALE = float(os.environ.get("PSNR_LR_SCALE", "1"))
+LR0 = 5e-4 * LR_SCALE
 E = MG.import_reference()
 torch.set_num_threads(threads)
 torch.set_default_dtype(dtype)
@@ -40,7 +44,7 @@ r = MG.build_ref(E, cfg, state)
 if dtype == torch.float64:
     r = r.double()
     r.dtype = torch.float64
-opt = torch.optim.Adam([p for p in r.parameters()], lr=5e-4)
+opt = torch.optim.Adam([p for p in r.parameters()], lr=LR0)
 sched = synth_scene.schedule(11, n_iter, n_rays)
 ev = {k: torch.from_numpy(v).to(dtype) for k, v in synth_scene.eval_batch().items()}
 
@@ -76,7 +80,7 @@ if os.path.exists(CKPT):
 for it in range(start, n_iter + 1):
     b = {k: torch.from_numpy(v).to(dtype) for k, v in sched[it - 1].items()}
     for g in opt.param_groups:
-        g["lr"] = 5e-4 * lr_factor(it)
+        g["lr"] = LR0 * lr_factor(it)
     opt.zero_grad()
     with torch.no_grad():
         d_i = r.ray_marching(b["rays"], max_points=r.net_chunk)
@@ -103,5 +107,5 @@ for it in range(start, n_iter + 1):
                         dtype=str(dtype), threads=threads), CKPT + ".tmp")
         os.replace(CKPT + ".tmp", CKPT)
 np.savez(os.path.join(REPO, "tests", "golden", out_name + ".npz"), curve=np.array(curve, np.float64), loss=np.array(losses, np.float64),
-         n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11, dtype=str(dtype), threads=threads)
+         n_iter=n_iter, n_rays=n_rays, weight_seed=7, sched_seed=11, dtype=str(dtype), threads=threads, lr_scale=LR_SCALE)
 print("saved")
