@@ -262,20 +262,32 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
 // ---- SDF network: value pass + geometry features + reverse sweep ------------------------------------------------------------------
 // SDFNetwork (endosurf.py:773-786) on x_c: sdf, the 256 geometry features (colour evaluations only) and the analytic reverse sweep
 // g_c = d sdf / d x_c (get_sdf_grad_from_canonical_space, :603-619).  A wave owns 32 points.  The reverse sweep needs
-// softplus'(z_l) = sigmoid(100 z_l) of every layer: the pre-activations z_0 .. z_6 (the accumulators at the end of a layer) go to
-// HBM in k-step order and come back through a SIDE stream of the weight pipeline -- 2 direct loads of 1 KB per wave and k-step
-// into their own ring of four k-steps, same barriers; z_7 is still in registers when the sweep starts.  The stack lives in
-// WS_S_ACT: [tile][wave][layer][k-step][piece][lane] x 16 B.
-constexpr int XS_ENC_LD = 41;       // floats per point row of the encoding / its adjoint (39 used; odd: conflict-free)
+// softplus'(z_l) of every layer: the layer inputs s_1 .. s_7 (= softplus(z_0 .. z_6), the operands this kernel builds anyway) go to
+// WS_S_ACT as ROW-MAJOR [8][Mp][256] stacks while they are built and come back through a SIDE stream of the weight pipeline -- 2 direct
+// loads of 16 B per lane and k-step (per-lane source addresses: this lane's row) into their own ring of four k-steps, same barriers;
+// softplus' = 1 - exp(-100 s) as in the fp32 kernels; z_7 is still in registers when the sweep starts.
+// SAVE (training): additionally enc6(x_c) -> WS_S_S0, s_8 -> WS_S_ACT[7], the adjoints rho_7 .. rho_0 of the pre-activations ->
+// WS_S_RHO (row-major; the operands of the reverse GEMMs) and the adjoint of the encoding -> WS_S_ADJEPS: with this family's SDF
+// kernels the four [8][Mp][256] stacks of the SDF network are row-major (the fp32 family keeps them in fragment order; wgrad.hip takes
+// the layout per operand).
+constexpr int XS_ENC_LD = 41;       // floats per point row of the encoding / its adjoint (40 used; odd: conflict-free)
 constexpr int XS_ZRING_BYTES = XR_RING * 4 * 2048;
 constexpr int XS_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XS_ZRING_BYTES + (128 * XS_ENC_LD + 9 * 256 + 256 + 4) * 4;
 static_assert(XS_LDS_BYTES <= 160 * 1024, "LDS carve");
 __device__ __forceinline__ float sigmoid100(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-144.26950408889634f * z)); }
+// softplus'(z) = sigmoid(100 z) recovered from s = softplus(z): 1 - exp(-100 s), series where that cancels (chain_common.h
+// softplus100_grad_from_s on the raw exp unit)
+__device__ __forceinline__ float dphi_from_s(float s) {
+    const float x = 100.f * s;
+    const float big = 1.f - __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+    return x < 0.02f ? x * (1.f - x * (0.5f - x * (1.f / 6.f))) : big;
+}
 
-template <bool DEFORM, bool COLOR>
+template <bool DEFORM, bool COLOR, bool SAVE>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                              float* __restrict__ ws_xc, float* __restrict__ ws_sdf, float* __restrict__ ws_feat,
-                                                             float* __restrict__ ws_gc, float* __restrict__ ws_go, float4* __restrict__ zst, int Mp) {
+                                                             float* __restrict__ ws_gc, float* __restrict__ ws_go, float* __restrict__ SACT,
+                                                             float* __restrict__ S0, float* __restrict__ RHO, float* __restrict__ ADJEPS, int Mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     unsigned char* zring = ldsr + XR_RING * XR_CHUNK_BYTES;
     float* encs = reinterpret_cast<float*>(zring + XS_ZRING_BYTES);                // [128 points][41]: enc6(x_c), later its adjoint
@@ -284,18 +296,16 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
-    const int point = blockIdx.x * 128 + wave * 32 + n;
-    constexpr bool live = true;                                // Mp is a multiple of 128 (workspace.h): every point of a block is a workspace row
-    constexpr bool wave_live = true;
+    const int point = blockIdx.x * 128 + wave * 32 + n;                            // a workspace row (Mp is a multiple of 128)
     float* erow = encs + (wave * 32 + n) * XS_ENC_LD;
     float x[3];
     if (DEFORM) {
-        const float* xc = ws_xc + (size_t)(live ? point : 0) * 3;
+        const float* xc = ws_xc + (size_t)point * 3;
         x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
     } else {
         float t, d[3];
         load_point(src, point, x, t, d);
-        if (live && hi == 0) { ws_xc[(size_t)point * 3] = x[0]; ws_xc[(size_t)point * 3 + 1] = x[1]; ws_xc[(size_t)point * 3 + 2] = x[2]; }
+        if (hi == 0) { ws_xc[(size_t)point * 3] = x[0]; ws_xc[(size_t)point * 3 + 1] = x[1]; ws_xc[(size_t)point * 3 + 2] = x[2]; }
     }
     for (int i = tid; i < 9 * 256; i += XR_THREADS) {
         const int l = i >> 8, f = i & 255;
@@ -315,8 +325,13 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
             erow[enc_index(3, i, 1, c)] = co;
         }
     }
-    if (hi == 0) { erow[0] = x[0]; erow[1] = x[1]; erow[2] = x[2]; }
+    if (hi == 0) { erow[0] = x[0]; erow[1] = x[1]; erow[2] = x[2]; erow[39] = 0.f; }
     __syncthreads();
+    const size_t lstride = (size_t)Mp * 256;
+    if (SAVE) {
+#pragma unroll
+        for (int k = 0; k < 20; k += 4) st4(S0 + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
+    }
     // logical k-steps: [0, 120) SF0 .. SF7, then (colour: SF8F,) SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0
     constexpr int KR0 = XR_SDF_FWD_CHUNKS + (COLOR ? 16 : 0);                       // first k-step of the reverse sweep
     WStream ws;
@@ -324,14 +339,14 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     ws.e0 = XR_SDF_FWD_CHUNKS; ws.b0 = XR_SDF_CHUNK0; ws.b1 = XR_SI_CHUNK0 + (COLOR ? 0 : 16);
     ws.start();
 
-    float4* zmine = zst + ((size_t)(blockIdx.x * 4 + wave) * 8 * 16 * 2) * 64 + lane;      // + ((layer * 16 + s) * 2 + piece) * 64
-    // the side stream: pre-activations of the layer whose softplus' the reverse GEMM of k-step kk needs
-    const auto side = [&](int kk, int t) {
+    float* Srow = SACT + (size_t)point * 256 + 4 * hi;                            // + layer Mp 256 + 16 s (+ 8): this lane's pieces
+    // the side stream: the layer input whose softplus' the reverse GEMM of k-step kk needs
+    const auto side = [&](int kk, int t, int) {
         if (t != 1 && t != 4) return;
         const int r = kk - (KR0 + 16);                       // SR7 reads z_7 from registers
-        if (r < 0 || r >= 8 * 16 || !wave_live) return;
+        if (r < 0 || r >= 8 * 16) return;
         const int gi = r >> 4, s = r & 15, layer = gi <= 2 ? 6 - gi : 7 - gi, piece = t == 4;     // SR6 SR5 SR4A SR4M SR3 SR2 SR1 SR0
-        const float4* srcp = zmine + ((layer * 16 + s) * 2 + piece) * 64;
+        const float* srcp = Srow + (size_t)layer * lstride + 16 * s + 8 * piece;                 // s_{layer+1} = softplus(z_layer)
         unsigned char* dst = zring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
@@ -346,47 +361,44 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return softplus100_native(P[b][4 * q + i]);
     };
-    const auto push_z = [&](int layer) {                     // z_layer = C, in the k-step order of the operand it becomes
-        if (!wave_live) return;
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int r0 = 8 * (s & 1) + 4 * pc;
-                zmine[((layer * 16 + s) * 2 + pc) * 64] = make_float4(C[s >> 1][r0], C[s >> 1][r0 + 1], C[s >> 1][r0 + 2], C[s >> 1][r0 + 3]);
-            }
-    };
-    push_z(0);
     copy8(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
-        gemm_r<16>(C, ws, act_val, side);
+        float* Sl = Srow + (size_t)(l - 1) * lstride;          // s_l = this GEMM's operand
+        gemm_rs<16>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { st_kstep(Sl, s, v); });
         if (l == 4) gemm_r<4>(C, ws, enc_val, side);           // NeRF skip: + encoding part (SF4A follows SF4M)
-        if (l < 7) push_z(l);
         copy8(P, C);
     }
     // P = z_7
     if (COLOR) {       // geometry features = rows 1 .. 256 of the last layer
         init8(C, biasL + 8 * 256, hi);
-        gemm_r<16>(C, ws, act_val, side);
-        if (live) {
-            float* fo = ws_feat + (size_t)point * 256;
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(fo + 32 * b + 8 * q + 4 * hi) = make_float4(C[b][4 * q], C[b][4 * q + 1], C[b][4 * q + 2], C[b][4 * q + 3]);
-        }
-    }
-    {
-        float s0 = 0.f;
+        float* S8 = Srow + (size_t)7 * lstride;
+        gemm_rs<16>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(S8, s, v); });
+        float* fo = ws_feat + (size_t)point * 256;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s0 = fmaf(w8L[32 * b + 8 * (r >> 2) + 4 * hi + (r & 3)], softplus100_native(P[b][r]), s0);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(fo + 32 * b + 8 * q + 4 * hi) = make_float4(C[b][4 * q], C[b][4 * q + 1], C[b][4 * q + 2], C[b][4 * q + 3]);
+    }
+    {
+        float s0 = 0.f;
+        float* S8 = Srow + (size_t)7 * lstride;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s4[i] = softplus100_native(P[b][4 * q + i]);
+                    s0 = fmaf(w8L[32 * b + 8 * q + 4 * hi + i], s4[i], s0);
+                }
+                if (SAVE && !COLOR) st4(S8 + 32 * b + 8 * q, s4[0], s4[1], s4[2], s4[3]);      // (with COLOR the feature GEMM's sink stored s_8)
+            }
         s0 += __shfl_xor(s0, 32);
-        if (hi == 0 && live) ws_sdf[point] = s0 + w8L[256];
+        if (hi == 0) ws_sdf[point] = s0 + w8L[256];
     }
     // ---- reverse sweep: rho_l = softplus'(z_l) . (adjoint of s_{l+1}),  adjoint of s_l = W_l^T rho_l ----
     const auto zero = [&](f32x16(&A)[8], int nb) {
@@ -396,33 +408,42 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
 #pragma unroll
                 for (int r = 0; r < 16; ++r) A[b][r] = 0.f;
     };
+    float* Rrow = RHO + (size_t)point * 256 + 4 * hi;
+    int lsave = 7;
+    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * lstride, s, v); };
     zero(C, 8);
-    gemm_r<16>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
+    gemm_rs<16>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return sigmoid100(P[b][4 * q + i]) * w8L[32 * b + 8 * q + 4 * hi + i];
-    }, side);
+    }, side, rsink);
     copy8(P, C);
-    int kb = 0;                                                  // first k-step of the running GEMM (its z slots)
+    int kb = 0;                                                  // first k-step of the running GEMM (its side-stream slots)
     const auto rho_val = [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
-        const float z = reinterpret_cast<const float*>(zring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
-        return sigmoid100(z) * P[b][4 * q + i];
+        const float sv = reinterpret_cast<const float*>(zring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
+        return dphi_from_s(sv) * P[b][4 * q + i];
     };
     f32x16 E[8];                                                 // adjoint of the encoding input (blocks 0, 1): skip part + layer 0
-    zero(E, 4);
+    zero(E, 2);
 #pragma unroll 1
     for (int l = 6; l >= 1; --l) {
+        lsave = l;
         if (l == 4) {                                            // encoding part of the skip layer's input adjoint, same operand rho_4
             kb = ws.k;
-            gemm_r<16, 1, true>(E, ws, rho_val, side);
+            gemm_rs<16, 0, true>(E, ws, rho_val, side, rsink);
+            kb = ws.k;
+            zero(C, 8);
+            gemm_r<16, 2, true>(C, ws, rho_val, side);
+        } else {
+            kb = ws.k;
+            zero(C, 8);
+            gemm_rs<16, 2, true>(C, ws, rho_val, side, rsink);
         }
-        kb = ws.k;
-        zero(C, 8);
-        gemm_r<16, 2, true>(C, ws, rho_val, side);
         copy8(P, C);
     }
     kb = ws.k;
-    gemm_r<16, 1, true>(E, ws, rho_val, side);                   // += W_0^T rho_0
+    lsave = 0;
+    gemm_rs<16, 0, true>(E, ws, rho_val, side, rsink);           // += W_0^T rho_0
     // g_c[j] = sum_k adj[k] * d enc_k / d x_j
     __syncthreads();                                             // everybody is done with the encoding rows
 #pragma unroll
@@ -432,7 +453,11 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
             const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
             if (f < 39) erow[f] = E[b][r];
         }
-    if (hi == 0 && live) {
+    if (SAVE) {      // (same wave: the LDS writes above are ordered before these reads; column 39 is the zero written at the start)
+#pragma unroll
+        for (int k = 0; k < 20; k += 4) st4(ADJEPS + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
+    }
+    if (hi == 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float gv = erow[j];
@@ -497,7 +522,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     ws.start();
 
     const float* frow = ws_feat + pl * 256;
-    const auto side = [&](int kk, int t) {                    // geometry features of k-step s of CF0F / CF4F
+    const auto side = [&](int kk, int t, int) {                    // geometry features of k-step s of CF0F / CF4F
         if (t != 1 && t != 4) return;
         int s = kk - XC_K_0F;
         if (s < 0 || s >= 16) s = kk - XC_K_4F;
@@ -594,10 +619,14 @@ static int infer_attrs() {
         if (int e = allow_big_lds(k_deform_jvp_x3r<true>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<false>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<true>, XI_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false, true>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<true, false>, XC_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<false, false>, XC_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<true, true>, XC_LDS_BYTES)) return e;
@@ -635,18 +664,29 @@ int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
     return hip_last("deform_vjp_x3r");
 }
 
-// all Mp points get sdf / g_c (/ g_o); the geometry features (m_feat > 0) are written for every point as well
-int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st) {
+// all Mp points get sdf / g_c (/ g_o); the geometry features (color) are written for every point as well
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, bool save, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
     ScopedTimer tm(KID_SDF_FWD_X3, src.M, st);
-    const dim3 grid((L.Mp + 127) / 128), block(XR_THREADS);
+    const dim3 grid(L.Mp / 128), block(XR_THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
     float* xc = ws + L.off[WS_XC]; float* sdf = ws + L.off[WS_SDF]; float* feat = ws + L.off[WS_FEAT]; float* gc = ws + L.off[WS_GC];
-    float* go = ws + L.off[WS_GO]; float4* zst = reinterpret_cast<float4*>(ws + L.off[WS_S_ACT]);
-#define ES_LAUNCH_SDF_X3R(D, Cc) hipLaunchKernelGGL((k_sdf_fwd_x3r<D, Cc>), grid, block, XS_LDS_BYTES, st, src, tb, pk, weff, xc, sdf, feat, gc, go, zst, L.Mp)
-    if (deform) { if (color) ES_LAUNCH_SDF_X3R(true, true); else ES_LAUNCH_SDF_X3R(true, false); }
-    else { if (color) ES_LAUNCH_SDF_X3R(false, true); else ES_LAUNCH_SDF_X3R(false, false); }
+    float* go = ws + L.off[WS_GO]; float* sact = ws + L.off[WS_S_ACT];
+    float* s0 = ws + L.off[WS_S_S0]; float* rho = ws + L.off[WS_S_RHO]; float* adj = ws + L.off[WS_S_ADJEPS];
+#define ES_LAUNCH_SDF_X3R(D, Cc, S) hipLaunchKernelGGL((k_sdf_fwd_x3r<D, Cc, S>), grid, block, XS_LDS_BYTES, st, src, tb, pk, weff, xc, sdf, feat, gc, go, sact, \
+                                                        s0, rho, adj, L.Mp)
+    const int v = (deform ? 4 : 0) | (color ? 2 : 0) | (save ? 1 : 0);
+    switch (v) {
+        case 0: ES_LAUNCH_SDF_X3R(false, false, false); break;
+        case 1: ES_LAUNCH_SDF_X3R(false, false, true); break;
+        case 2: ES_LAUNCH_SDF_X3R(false, true, false); break;
+        case 3: ES_LAUNCH_SDF_X3R(false, true, true); break;
+        case 4: ES_LAUNCH_SDF_X3R(true, false, false); break;
+        case 5: ES_LAUNCH_SDF_X3R(true, false, true); break;
+        case 6: ES_LAUNCH_SDF_X3R(true, true, false); break;
+        default: ES_LAUNCH_SDF_X3R(true, true, true); break;
+    }
 #undef ES_LAUNCH_SDF_X3R
     return hip_last("sdf_fwd_x3r");
 }

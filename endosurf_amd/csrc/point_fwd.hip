@@ -545,7 +545,7 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 // infer_x3r.hip / query_x3.hip
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
 int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
-int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st);
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, bool save, hipStream_t st);
 int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, bool save, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
@@ -564,16 +564,17 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour | VJP
         const void* pr = packed_x3r_part(packed_x3);
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, false, st)) return e; }
-        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, st)) return e;
+        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, false, st)) return e;
         if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, false, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, false, st) : hip_last("point_forward");
     }
     if ((flags & PF_X3_CHAIN) && (flags & PF_SAVE) && packed_x3) {
-        // opt-in split-precision TRAINING chain: the deformation family runs on the register-resident core and keeps what the backward
-        // needs in the fp32 kernels' layouts (masks excepted: PF_X3_CHAIN tells the backward); SDF and colour networks: fp32 kernels
+        // opt-in split-precision TRAINING chain: all four launches on the register-resident core, keeping what the backward needs in
+        // the fp32 kernels' buffers (row-major stacks; the ReLU mask words and the SDF stacks' order are this family's: PF_X3_CHAIN
+        // tells the backward and the weight-gradient GEMMs)
         const void* pr = packed_x3r_part(packed_x3);
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, true, st)) return e; }
-        { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, true, st)) return e;
         if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, true, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, true, st) : hip_last("point_forward");
     }

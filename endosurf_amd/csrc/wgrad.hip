@@ -782,21 +782,23 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         if (int e = launch_group(g, n, sm, 0, x3 ? KID_WGRAD_D_X3 : KID_WGRAD_D, M, det, x3, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
-        // kernels (s, rho, tau, zbar) are fragment-ordered (their epilogues load AND store them: one dwordx4 per quad)
+        // kernels (s, rho, tau, zbar) are fragment-ordered when the fp32 kernels wrote them (their epilogues load AND store them: one
+        // dwordx4 per quad) and row-major when the split-precision training chain did (PF_X3_CHAIN, infer_x3r.hip / train_x3r.hip)
+        const int fr = (flags & PF_X3_CHAIN) ? 0 : 1;
         n = 0;
-        add(B(WS_S_S0), 64, B(WS_S_ZB), 256, Mp, 39, 256, dW(NET_S, 0), 39, dB(NET_S, 0), 1, 0, 1);
-        add(B(WS_S_TAU0), 64, B(WS_S_RHO), 256, Mp, 39, 256, dW(NET_S, 0), 39, nullptr, 1, 0, 1);
+        add(B(WS_S_S0), 64, B(WS_S_ZB), 256, Mp, 39, 256, dW(NET_S, 0), 39, dB(NET_S, 0), 1, 0, fr);
+        add(B(WS_S_TAU0), 64, B(WS_S_RHO), 256, Mp, 39, 256, dW(NET_S, 0), 39, nullptr, 1, 0, fr);
         for (int l = 1; l <= 7; ++l) {
             const int K = LAYER_K[NET_S][l];
-            add(B(WS_S_ACT) + (size_t)(l - 1) * t256, 256, B(WS_S_ZB) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, dB(NET_S, l), 1, 1, 1);
-            add(B(WS_S_TAU) + (size_t)(l - 1) * t256, 256, B(WS_S_RHO) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, nullptr, 1, 1, 1);
+            add(B(WS_S_ACT) + (size_t)(l - 1) * t256, 256, B(WS_S_ZB) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, dB(NET_S, l), 1, fr, fr);
+            add(B(WS_S_TAU) + (size_t)(l - 1) * t256, 256, B(WS_S_RHO) + (size_t)l * t256, 256, Mp, 256, 256, dW(NET_S, l), K, nullptr, 1, fr, fr);
             if (l == 4) {   // skip layer: encoding columns 256..294
-                add(B(WS_S_S0), 64, B(WS_S_ZB) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, 1);
-                add(B(WS_S_TAU0), 64, B(WS_S_RHO) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, 1);
+                add(B(WS_S_S0), 64, B(WS_S_ZB) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, fr);
+                add(B(WS_S_TAU0), 64, B(WS_S_RHO) + (size_t)4 * t256, 256, Mp, 39, 256, dW(NET_S, 4) + 256, K, nullptr, 1, 0, fr);
             }
         }
         if (flags & PF_COLOR)   // feature rows 1..256 of the last layer
-            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1, 1, 0);
+            add(B(WS_S_ACT) + (size_t)7 * t256, 256, B(WS_FEATBAR), 256, Mc, 256, 256, dW(NET_S, 8) + 256, 256, dB(NET_S, 8) + 1, 1, fr, 0);
         // row 0 of the last layer: sdfbar^T s_8  +  column sums of tau_8 (adjoint of the reverse sweep's seed row)
         ns = 0;
         if (flags & PF_DEFORM) {     // last deformation layer (3 outputs): value + J d rows here, (tau_8, g_c) pair with the colour launch
@@ -804,8 +806,8 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
             small(B(WS_D_U) + (size_t)7 * r256, 256, B(WS_D_A8), 4, 2 * Mp, 256, 3, dW(NET_D, 8), 256, dB(NET_D, 8), 2);
             if (!(flags & PF_COLOR)) small(B(WS_D_T) + (size_t)7 * t256, 256, B(WS_GC), 3, Mp, 256, 3, dW(NET_D, 8), 256, nullptr, 1);
         }
-        small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, 1);   // real rows only: d_sdf is [M]
-        small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, 1);
+        small(B(WS_S_ACT) + (size_t)7 * t256, 256, d_sdf, 1, M, 256, 1, dW(NET_S, 8), 256, dB(NET_S, 8), 1, fr);   // real rows only: d_sdf is [M]
+        small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, fr);
         if (int e = launch_group(g, n, sm, ns, x3 ? KID_WGRAD_S_X3 : KID_WGRAD_S, M, det, x3, st)) return e;
     }
     if (flags & PF_COLOR) {

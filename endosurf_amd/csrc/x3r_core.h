@@ -124,10 +124,12 @@ __device__ __forceinline__ void build_frag(FragB& b, VAL&& val, int s, SINK&& si
 // between the MFMAs of k-step s.  MFMA order: term-major over groups of 4 accumulators -- consecutive MFMAs never share an
 // accumulator (an instruction issued between two MFMAs of one accumulate chain costs ~40 cycles, between independent ones ~6), the
 // six partial products of an accumulator still arrive smallest first.  KG is even and ws.k is even on entry.
-struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+struct NoSide { __device__ __forceinline__ void operator()(int, int, int) const {} };
 // LATE (values that depend on data landing at this k-step's barrier): all 8 operand elements are built in group 1, two per slot;
 // otherwise 8 of the 12 (group, term) slots build one element each.  STAGE: this k-step issues the direct loads of the next pair.
-template <int G, bool MFMA, bool LATE, bool STAGE, class VAL, class SIDE>
+// side(kk, t, sloc): slot t of the k-step that stages the loads of k-step kk (logical) = k-step sloc of the running GEMM (compile-time after
+// unrolling; sloc >= KG: the first k-steps of whatever follows it).  NF: feature blocks of the group that are computed (4, or 2 with NG = 0).
+template <int G, bool MFMA, bool LATE, bool STAGE, int NF, class VAL, class SIDE>
 __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const FragA& a, const FragB& b, FragB& nb, float (&v)[8], VAL&& val, int snext,
                                            bool more, SIDE&& side) {
     // smallest terms first: (l,h) (m,m) (h,l) | (m,h) (h,m) | (h,h)
@@ -138,13 +140,13 @@ __device__ __forceinline__ void mfma_group(f32x16 (&C)[8], WStream& ws, const Fr
 #ifndef XR_NO_MFMA
         if (MFMA)
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < NF; ++f)
                 C[4 * G + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[f][TA[t]]), __builtin_bit_cast(bf16x8, bt),
                                                                       C[4 * G + f], 0, 0, 0);
 #endif
         if (STAGE) {
-            ws.piece(ws.k + 2 + G, t);     // one direct load per four MFMAs
-            side(ws.k + 2 + G, t);         // a kernel's own per-k-step operand stream (same slots, same barriers)
+            ws.piece(ws.k + 2 + G, t);                     // one direct load per four MFMAs
+            side(ws.k + 2 + G, t, snext + 1 + G);          // a kernel's own per-k-step operand stream (same slots, same barriers)
         }
 #ifndef XR_NO_VALU
         if (more && t < 4) {
@@ -176,15 +178,16 @@ __device__ __forceinline__ void kstep_r(f32x16 (&C)[8], WStream& ws, FragB& b, V
     float v[8];
     FragA a1;
     ws.read_group(a1, ws.k, 1);
-    mfma_group<0, true, LATE && ODD, !ODD>(C, ws, ws.a0, b, nb, v, val, snext, more, side);
+    mfma_group<0, true, LATE && ODD, !ODD, (NG == 0 ? 2 : 4)>(C, ws, ws.a0, b, nb, v, val, snext, more, side);
     if (ODD) ws.landed_barrier();
     ws.read_group(ws.a0, ws.k + 1, 0);
-    mfma_group<1, NG == 2, LATE && ODD, !ODD>(C, ws, a1, b, nb, v, val, snext, more, side);
+    mfma_group<1, NG == 2, LATE && ODD, !ODD, 4>(C, ws, a1, b, nb, v, val, snext, more, side);
     if (more) sink(snext, v);
     b = nb;
     ++ws.k;
 }
-// NG = 1: only accumulator group 0 (features 0 .. 127) is computed -- the stream, its barriers and the operand build are unchanged.
+// NG = 1: only accumulator group 0 (features 0 .. 127) is computed, NG = 0: only its first two blocks (features 0 .. 63) -- the stream,
+// its barriers and the operand build are unchanged.
 // LATE: val(s, .) of an EVEN k-step s reads data that lands with the barrier inside k-step s - 1 (a side stream): those operands are
 // built after that barrier.
 template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE, class SINK>

@@ -25,6 +25,17 @@ def _buf(ctx, name, rows, width, layers=1):
     return ctx.ws[off:off + layers * rows * width].view(layers, rows, width)
 
 
+def _stack(ctx, name, frag):
+    """[8][Mp][256] view of one of the SDF network's stacks: row-major in the split-precision family, accumulator-fragment order
+    (csrc/chain_common.h frag_off: [64-row tile][w][ri][ni][q][hi][lo] x 4 rows) in the fp32 family."""
+    Mp = ctx.Mp
+    a = _buf(ctx, name, Mp, 256, 8)
+    if not frag:
+        return a
+    t = a.view(8, Mp // 64, 4, 2, 2, 4, 2, 32, 4)              # L, tile, w, ri, ni, q, hi, lo, i
+    return t.permute(0, 1, 3, 5, 6, 8, 2, 4, 7).reshape(8, Mp, 256)      # rows (tile, ri, q, hi, i), columns (w, ni, lo)
+
+
 def _points(M, seed):
     rng = np.random.default_rng(seed)
     x = torch.from_numpy(rng.uniform(-0.8, 0.8, size=(M, 3)).astype(np.float32)).cuda()
@@ -65,7 +76,13 @@ def test_forward_with_saves_matches_fp32_buffers(mode, M, color):
         _close(a[:, :real, :cols], b[:, :real, :cols], 2e-6)
     # layer 3 of the deformation network has 204 outputs: its adjoint columns beyond are exact zeros in both families
     assert float(_buf(ctx, "D_R", Mp, 256, 8)[3, :M, 204:].abs().max()) == 0.0
+    assert qd(ctx.view("gc"), ref.view("gc")) < 1e-4
+    for name in ("S_S0", "S_ADJEPS"):
+        _close(_buf(ctx, name, Mp, 64)[:, :M, :39], _buf(ref, name, Mp, 64)[:, :M, :39], 2e-5)
+    for name in ("S_ACT", "S_RHO"):
+        _close(_stack(ctx, name, False)[:, :M], _stack(ref, name, True)[:, :M], 2e-5)
     if color:
+        assert qd(ctx.view("feat"), ref.view("feat")) < 5e-5
         assert qd(ctx.view("rgb"), ref.view("rgb"), 0.98) < 5e-5
         _close(_buf(ctx, "C_IN", Mp, 128)[:, :M, :93], _buf(ref, "C_IN", Mp, 128)[:, :M, :93], 5e-5, q=0.99, frac_bad=2e-2)      # incl. enc4(d_c): J d flips
         _close(_buf(ctx, "C_H", Mp, 256, 8)[:, :M], _buf(ref, "C_H", Mp, 256, 8)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
@@ -101,6 +118,10 @@ def test_backward_matches_fp32_chain_and_saved_adjoints(mode, color):
         _close(a[:, :real, :cols], b[:, :real, :cols], 5e-6, frac_bad=5e-3)
     a8, b8 = _buf(ctx, "D_A8", 2 * Mp, 4)[0, :2 * M], _buf(ref, "D_A8", 2 * Mp, 4)[0, :2 * M]
     _close(a8, b8, 2e-5, q=0.99, frac_bad=2e-2)          # the J d rows are seeded by the colour network (d_c flips)
+    _close(_buf(ctx, "S_TAU0", Mp, 64)[:, :M, :39], _buf(ref, "S_TAU0", Mp, 64)[:, :M, :39], 2e-5, q=0.99, frac_bad=2e-2)
+    for name in ("S_TAU", "S_ZB"):
+        _close(_stack(ctx, name, False)[:, :M], _stack(ref, name, True)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
+    _close(_buf(ctx, "XCBAR", Mp, 3)[:, :M], _buf(ref, "XCBAR", Mp, 3)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
     if color:
         for name, width, layers in (("C_Y", 256, 8), ("C_Y8", 4, 1), ("FEATBAR", 256, 1), ("XCBAR_C", 3, 1), ("GCBAR_C", 3, 1), ("VBAR_C", 3, 1)):
             _close(_buf(ctx, name, Mp, width, layers)[:, :M], _buf(ref, name, Mp, width, layers)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
