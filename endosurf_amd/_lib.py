@@ -101,6 +101,7 @@ PROTOTYPES = {
 
 ABI_VERSION = 4
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
+PF_X3_SDF = 64
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 
 _lib = None

@@ -358,7 +358,7 @@ static int render_points(const es_render_args* a, PointSrc& ps, int& flags) {
                "es_render arguments");
     ps = PointSrc{};
     ps.rays = a->c.rays; ps.z = a->scratch; ps.mode = 1; ps.n_per_ray = a->c.S; ps.ldz = a->c.S; ps.M = a->c.N * a->c.S;
-    flags = (a->flags & (ES_PF_DEFORM | ES_PF_SAVE | ES_PF_X3)) | ES_PF_COLOR;      // ES_PF_X3: opt-in split-precision weight gradients
+    flags = (a->flags & (ES_PF_DEFORM | ES_PF_SAVE | ES_PF_X3 | ES_PF_X3_SDF)) | ES_PF_COLOR;      // ES_PF_X3: opt-in split-precision weight gradients
     return ST_OK;
 }
 static CompositeArgs render_composite_args(const es_render_args* a, int flags) {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
         u32x4 mk = {0u, 0u, 0u, 0u};
         init(C, l);
         float* Ul = U + ((size_t)(l - 1) * rows2 + urow) * 256 + 4 * hi;      // u_l = this GEMM's operand
-        gemm_rs<16>(C, ws, [&](int s, int j) -> float {
+        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float z = P[b][4 * q + i];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     const size_t rstride = (size_t)Mp * 256;
     int lsave = 7;
     const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * rstride, s, v); };      // (Mp is a multiple of 128: every point of the block is a row)
-    gemm_rs<16>(C, ws, [&](int s, int j) -> float {
+    gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], g[0], fmaf(w8L[256 + f], g[1], w8L[512 + f] * g[2]));
@@ -218,19 +218,19 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
         };
         lsave = l;
         if (l == 3) {                           // 204 outputs of layer 3: 14 k-steps (the rest is zero padding in DR3)
-            gemm_rs<14>(C, ws, val, NoSide(), rsink);
+            gemm_rs<14, 2, false, (SAVE ? 2 : 0)>(C, ws, val, NoSide(), rsink);
             if (SAVE) {                         // features 224 .. 255 of r_3 are zero like 204 .. 223
                 const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 st_kstep(Rrow + 3 * rstride, 14, z8); st_kstep(Rrow + 3 * rstride, 15, z8);
             }
-        } else gemm_rs<16>(C, ws, val, NoSide(), rsink);
+        } else gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, val, NoSide(), rsink);
         copy8(P, C);
     }
     // r_0 = mask_0 . (adjoint of h_0);  adjoint of the encoding += W_0^T r_0 (52 outputs: accumulator group 0 only)
     mk = masks[mrow];
     zero(C);
     lsave = 0;
-    gemm_rs<16, 1>(C, ws, [&](int s, int j) -> float {
+    gemm_rs<16, 1, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;
     }, NoSide(), rsink);
@@ -275,14 +275,6 @@ constexpr int XS_ZRING_BYTES = XR_RING * 4 * 2048;
 constexpr int XS_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XS_ZRING_BYTES + (128 * XS_ENC_LD + 9 * 256 + 256 + 4) * 4;
 static_assert(XS_LDS_BYTES <= 160 * 1024, "LDS carve");
 __device__ __forceinline__ float sigmoid100(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-144.26950408889634f * z)); }
-// softplus'(z) = sigmoid(100 z) recovered from s = softplus(z): 1 - exp(-100 s), series where that cancels (chain_common.h
-// softplus100_grad_from_s on the raw exp unit)
-__device__ __forceinline__ float dphi_from_s(float s) {
-    const float x = 100.f * s;
-    const float big = 1.f - __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
-    return x < 0.02f ? x * (1.f - x * (0.5f - x * (1.f / 6.f))) : big;
-}
-
 template <bool DEFORM, bool COLOR, bool SAVE>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                              float* __restrict__ ws_xc, float* __restrict__ ws_sdf, float* __restrict__ ws_feat,
@@ -366,7 +358,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
         float* Sl = Srow + (size_t)(l - 1) * lstride;          // s_l = this GEMM's operand
-        gemm_rs<16>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { st_kstep(Sl, s, v); });
+        gemm_rs<16, 2, false, 2>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { st_kstep(Sl, s, v); });
         if (l == 4) gemm_r<4>(C, ws, enc_val, side);           // NeRF skip: + encoding part (SF4A follows SF4M)
         copy8(P, C);
     }
@@ -374,7 +366,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     if (COLOR) {       // geometry features = rows 1 .. 256 of the last layer
         init8(C, biasL + 8 * 256, hi);
         float* S8 = Srow + (size_t)7 * lstride;
-        gemm_rs<16>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(S8, s, v); });
+        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(S8, s, v); });
         float* fo = ws_feat + (size_t)point * 256;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
@@ -412,7 +404,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     int lsave = 7;
     const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * lstride, s, v); };
     zero(C, 8);
-    gemm_rs<16>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
+    gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return sigmoid100(P[b][4 * q + i]) * w8L[32 * b + 8 * q + 4 * hi + i];
     }, side, rsink);
@@ -430,20 +422,20 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
         lsave = l;
         if (l == 4) {                                            // encoding part of the skip layer's input adjoint, same operand rho_4
             kb = ws.k;
-            gemm_rs<16, 0, true>(E, ws, rho_val, side, rsink);
+            gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);
             kb = ws.k;
             zero(C, 8);
             gemm_r<16, 2, true>(C, ws, rho_val, side);
         } else {
             kb = ws.k;
             zero(C, 8);
-            gemm_rs<16, 2, true>(C, ws, rho_val, side, rsink);
+            gemm_rs<16, 2, true, (SAVE ? 2 : 0)>(C, ws, rho_val, side, rsink);
         }
         copy8(P, C);
     }
     kb = ws.k;
     lsave = 0;
-    gemm_rs<16, 0, true>(E, ws, rho_val, side, rsink);           // += W_0^T rho_0
+    gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);           // += W_0^T rho_0
     // g_c[j] = sum_k adj[k] * d enc_k / d x_j
     __syncthreads();                                             // everybody is done with the encoding rows
 #pragma unroll
@@ -563,7 +555,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     float* Hrow = CH + pl * 256 + 4 * hi;                     // + (l - 1) Mp 256: h_l of this lane's point
     float* Irow = CIN + pl * 128 + 4 * hi;
     init8(C, biasL, hi);
-    gemm_rs<6>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Irow, s, v); });
+    gemm_rs<6, 2, false, (SAVE ? 2 : 0)>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Irow, s, v); });
     kb = ws.k;
     gemm_r<16, 2, true>(C, ws, feat_val, side);
     copy8(P, C);
@@ -572,7 +564,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
         init8(C, biasL + l * 256, hi);
         float* Hl = Hrow + (size_t)(l - 1) * hstride;
         mk = u32x4{0u, 0u, 0u, 0u};
-        gemm_rs<16>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Hl, s, v); });
+        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Hl, s, v); });
         if (SAVE) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
         if (l == 4) {       // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
             gemm_r<6>(C, ws, small_val, side);

@@ -651,7 +651,8 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
         const void* pr = packed_x3r_part(packed_x3);
         if (flags & PF_COLOR) { if (int e = color_bwd_x3r(src, pr, weff, ws, a.L, deform, a.M_color, d_rgb, st)) return e; }
         if (deform) { if (int e = deform_tan_x3r(src, pr, weff, ws, a.L, d_go, st)) return e; }
-        if (int e = sdf_bwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, a.M_color, d_sdf, d_go, st)) return e;
+        if (flags & PF_X3_SDF) { if (int e = sdf_bwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, a.M_color, d_sdf, d_go, st)) return e; }
+        else { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
         if (deform) { if (int e = deform_bwd_x3r(pr, weff, ws, a.L, src.M, a.M_color, st)) return e; }
         return hip_last("point_backward_chains");
     }

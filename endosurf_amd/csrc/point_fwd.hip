@@ -574,7 +574,8 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         // tells the backward and the weight-gradient GEMMs)
         const void* pr = packed_x3r_part(packed_x3);
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, true, st)) return e; }
-        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, true, st)) return e;
+        if (flags & PF_X3_SDF) { if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, true, st)) return e; }
+        else { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
         if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, true, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, true, st) : hip_last("point_forward");
     }

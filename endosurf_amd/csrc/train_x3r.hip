@@ -91,7 +91,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
         const u32x4 mk = masks[((size_t)(l - 1) * Mp) * 2 + mrow];
         float* Tl = Trow + (size_t)(l - 1) * tstride;      // tau_l = this GEMM's operand
         zero8(C);
-        gemm_rs<16>(C, ws, [&](int s, int j) -> float {
+        gemm_rs<16, 2, false, 2>(C, ws, [&](int s, int j) -> float {
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float h = mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;      // layer 3: mask bits of features >= 204 are 0
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
     f32x16 P[8], C[8];
     // abar_7 = mask_7 . (W8^T abar_8)  ->  adjoint of h_6 = W_7^T abar_7
     zero8(C);
-    gemm_rs<16>(C, ws, [&](int s, int j) -> float {
+    gemm_rs<16, 2, false, 2>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], a8[0], fmaf(w8L[256 + f], a8[1], w8L[512 + f] * a8[2]));
@@ -179,10 +179,10 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
         };                                                                   // encoding part carries no parameter gradient)
         lsave = l;
         if (l == 3) {
-            gemm_rs<14>(C, ws, val, NoSide(), asink);
+            gemm_rs<14, 2, false, 2>(C, ws, val, NoSide(), asink);
             const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             st_kstep(Arow + 3 * astride, 14, z8); st_kstep(Arow + 3 * astride, 15, z8);
-        } else gemm_rs<16>(C, ws, val, NoSide(), asink);
+        } else gemm_rs<16, 2, false, 2>(C, ws, val, NoSide(), asink);
         copy8(P, C);
     }
     // abar_0 = mask_0 . (W_1^T abar_1): no further GEMM (the adjoint of the encoding input has no parameter gradient)
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
     const auto ysink = [&](int s, const float (&v)[8]) { st_kstep(Yrow + lsave * ystride, s, v); };
     f32x16 P[8], C[8];
     zero8(C);
-    gemm_rs<16>(C, ws, [&](int s, int j) -> float {               // ybar_7 = mask_7 . (U8^T ybar_8)
+    gemm_rs<16, 2, false, 2>(C, ws, [&](int s, int j) -> float {               // ybar_7 = mask_7 . (U8^T ybar_8)
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], y8[0], fmaf(w8L[256 + f], y8[1], w8L[512 + f] * y8[2]));
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
         lsave = l;
         if (l == 4 || l == 0) {          // adjoint of the network input: feature part (256), then small part (93: accumulator group 0)
             zero8(C);
-            gemm_rs<16>(C, ws, val, NoSide(), ysink);
+            gemm_rs<16, 2, false, 2>(C, ws, val, NoSide(), ysink);
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
             gemm_r<16>(C, ws, val);       // hidden part of the skip layer's input
         } else {
             zero8(C);
-            gemm_rs<16>(C, ws, val, NoSide(), ysink);
+            gemm_rs<16, 2, false, 2>(C, ws, val, NoSide(), ysink);
         }
         copy8(P, C);
     }
@@ -352,11 +352,6 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
 // two k-steps ahead into four rotating register sets.  All stacks row-major (this family's SDF layout, see k_sdf_fwd_x3r).
 constexpr int XSB_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XR_RING * 4 * 2048 + (128 * 41 + 256 + 4) * 4;
 static_assert(XSB_LDS_BYTES <= 160 * 1024, "LDS carve");
-__device__ __forceinline__ float dphi_from_s_t(float s) {      // softplus' from the softplus output: 1 - exp(-100 s), series where that cancels
-    const float x = 100.f * s;
-    const float big = 1.f - __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
-    return x < 0.02f ? x * (1.f - x * (0.5f - x * (1.f / 6.f))) : big;
-}
 __device__ __forceinline__ void ld8(float (&r)[8], const float* p) {      // the two 16-B pieces of a k-step's operand in a row-major row (p holds + 4 hi)
     const v4f_frag a = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(p));
     const v4f_frag b = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(p + 8));
@@ -439,7 +434,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tab
     const auto tau_val = [&](int s, int j) -> float {            // tau_l = phi'(z_{l-1}) pi_{l-1};  zeta_{l-1} alongside
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const float sv = reinterpret_cast<const float*>(sring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
-        const float dphi = dphi_from_s_t(sv), pi = P[b][4 * q + i];
+        const float dphi = dphi_from_s(sv), pi = P[b][4 * q + i];
         z2v[j] = 100.f * (1.f - dphi) * rb[s & 3][j] * pi;
         return dphi * pi;
     };
@@ -452,7 +447,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tab
         lcur = l;
         kb = ws.k;
         zero8(C);
-        gemm_rs<16, 2, true>(C, ws, tau_val, side, tsink);
+        gemm_rs<16, 2, true, 4>(C, ws, tau_val, side, tsink);
         if (l == 4) gemm_r<4>(C, ws, enc_val, side);              // NeRF skip: + W_4[:, 256:] tau_0
         copy8(P, C);
     }
@@ -470,7 +465,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tab
                 float t4[4], z4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float dphi = dphi_from_s_t(sv[i]), pi = P[b][4 * q + i];
+                    const float dphi = dphi_from_s(sv[i]), pi = P[b][4 * q + i];
                     t4[i] = dphi * pi;
                     z4[i] = 100.f * (1.f - dphi) * rv[i] * pi;
                 }
@@ -544,7 +539,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_rev_x3r(Tabs tb, const u3
     const auto zb_val = [&](int s, int j) -> float {             // zbar_l = phi'(z_l) sbar_{l+1} + zeta_l
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const float sv = reinterpret_cast<const float*>(sring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
-        return fmaf(dphi_from_s_t(sv), P[b][4 * q + i], rb[s & 3][j]);
+        return fmaf(dphi_from_s(sv), P[b][4 * q + i], rb[s & 3][j]);
     };
     const auto zsink = [&](int s, const float (&v)[8]) { st_kstep(Zrow + (size_t)lsave * lstride, s, v); };
     f32x16 E[8];                                                 // adjoint of the encoding input (blocks 0, 1): skip part + layer 0
@@ -561,12 +556,12 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_rev_x3r(Tabs tb, const u3
         }
         kb = ws.k;
         zero8(C);
-        gemm_rs<16, 2, true>(C, ws, zb_val, side, zsink);
+        gemm_rs<16, 2, true, 2>(C, ws, zb_val, side, zsink);
         copy8(P, C);
     }
     kb = ws.k;
     lsave = 0;
-    gemm_rs<16, 0, true>(E, ws, zb_val, side, zsink);            // += W_0^T zbar_0
+    gemm_rs<16, 0, true, 2>(E, ws, zb_val, side, zsink);            // += W_0^T zbar_0
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 2; ++b)

@@ -73,8 +73,15 @@ struct WStream {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 #endif
     }
+    // nst: vector-memory STORES the kernel issued after the last load of the pair that is landing (the sink of the even k-step: it runs
+    // after that k-step's staging slots, and the odd k-step issues nothing before its barrier).  vmcnt counts loads and stores of gfx9 in
+    // issue order, so vmcnt(nst) waits for every load while the youngest stores keep draining over the next k-step instead of being
+    // acknowledged within half of one.
+    int nst = 0;
     __device__ __forceinline__ void landed_barrier() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (nst == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if (nst == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifndef XR_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
@@ -190,9 +197,12 @@ __device__ __forceinline__ void kstep_r(f32x16 (&C)[8], WStream& ws, FragB& b, V
 // its barriers and the operand build are unchanged.
 // LATE: val(s, .) of an EVEN k-step s reads data that lands with the barrier inside k-step s - 1 (a side stream): those operands are
 // built after that barrier.
-template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE, class SINK>
+// NST: vector-memory store instructions one call of ``sink`` issues (0: unknown / none -> the barriers wait for everything)
+template <int KG, int NG = 2, bool LATE = false, int NST = 0, class VAL, class SIDE, class SINK>
 __device__ __forceinline__ void gemm_rs(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side, SINK&& sink) {
     static_assert(KG % 2 == 0, "k-step pairs");
+    static_assert(NST == 0 || NST == 2 || NST == 4, "store counts landed_barrier knows");
+    ws.nst = NST;
     FragB b;
     build_frag(b, val, 0, sink);
 #pragma unroll
@@ -200,9 +210,10 @@ __device__ __forceinline__ void gemm_rs(f32x16 (&C)[8], WStream& ws, VAL&& val, 
         kstep_r<NG, LATE, false>(C, ws, b, val, side, sink, 2 * sp + 1, true);
         kstep_r<NG, LATE, true>(C, ws, b, val, side, sink, 2 * sp + 2, 2 * sp + 2 < KG);
     }
+    ws.nst = 0;
 }
 template <int KG, int NG = 2, bool LATE = false, class VAL, class SIDE>
-__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side) { gemm_rs<KG, NG, LATE>(C, ws, val, side, NoSink()); }
+__device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val, SIDE&& side) { gemm_rs<KG, NG, LATE, 0>(C, ws, val, side, NoSink()); }
 template <int KG, int NG = 2, class VAL>
 __device__ __forceinline__ void gemm_r(f32x16 (&C)[8], WStream& ws, VAL&& val) { gemm_r<KG, NG, false>(C, ws, val, NoSide()); }
 
@@ -221,10 +232,28 @@ __device__ __forceinline__ void copy8(f32x16 (&P)[8], const f32x16 (&C)[8]) {
     for (int b = 0; b < 8; ++b) P[b] = C[b];
 }
 
-// four consecutive features of one row of a row-major [rows][256] stack (streamed once: non-temporal)
+// softplus'(z) = sigmoid(100 z) recovered from s = softplus(z): 1 - exp(-100 s), series where that cancels (chain_common.h
+// softplus100_grad_from_s on the raw exp unit).  The select is written as v_cmp + v_cndmask: left to the compiler, the ternary becomes a
+// divergent branch per element in the middle of the MFMA stream.
+__device__ __forceinline__ float dphi_from_s(float s) {
+    const float x = 100.f * s;
+    const float big = 1.f - __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+    const float ser = x * (1.f - x * (0.5f - x * (1.f / 6.f)));
+    float r;
+    asm("v_cmp_gt_f32 vcc, 0x3ca3d70a, %3\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(big), "v"(ser), "v"(x) : "vcc");      // 0.02 > x ? ser : big
+    return r;
+}
+
+// four consecutive features of one row of a row-major [rows][256] stack.  A row's 128-B line is completed by four such stores (two lane
+// halves x two pieces x two k-steps): ES_X3R_NT_STORES=1 (dev builds) marks them non-temporal like the fp32 kernels' stream-outs; the
+// default leaves them to the L2's write combining (measured: the non-temporal form wrote 1.5-1.66x the bytes at ~2.3 TB/s)
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
     const v4f_frag t = {a, b, c, d};
+#ifdef ES_X3R_NT_STORES
     __builtin_nontemporal_store(t, reinterpret_cast<v4f_frag*>(p));
+#else
+    *reinterpret_cast<v4f_frag*>(p) = t;
+#endif
 }
 // the operand of k-step s (8 values: features 16 s + 4 hi .. + 3 and 16 s + 8 + 4 hi .. + 3) into a row whose base already holds + 4 hi
 __device__ __forceinline__ void st_kstep(float* row_hi, int s, const float (&v)[8]) {

@@ -50,6 +50,8 @@ class Engine:
         # split-precision mode: grad-enabled evaluations run the split-precision TRAINING chain (infer_x3r.hip with saves +
         # train_x3r.hip); False keeps the fp32 chain kernels under the split-precision queries / weight gradients (round-2 behaviour)
         self.x3_train_chain = os.environ.get("ES_X3_TRAIN", "1") not in ("0", "", "false", "False")
+        # ... including the SDF network's training kernels (experimental: parity-tested, but slower than the fp32 SDF kernels)
+        self.x3_sdf_chain = os.environ.get("ES_X3_SDF", "0") not in ("0", "", "false", "False")
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -340,6 +342,9 @@ def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, like_s
         # opt-in: the launches of a large evaluation in split precision -- csrc/infer_x3r.hip without PF_SAVE; with PF_SAVE the
         # split-precision TRAINING chain, whose workspace must go through es_point_backward_x3 (``ctx.x3_chain``)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
+        if save and self.x3_sdf_chain:
+            flags |= _lib.PF_X3_SDF
+            ctx.flags = flags            # no effect on the layout's offsets; the backward reads the family from it
         check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(px3), ptr(weff), ptr(ctx.ws), flags, int(m_color),
                                            self.st()), "es_point_forward_x3")
         ctx.x3_chain = save
