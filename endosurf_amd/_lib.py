@@ -77,6 +77,7 @@ PROTOTYPES = {
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_color_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _P]),
     "es_point_forward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P]),
+    "es_gemm_atb": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "es_point_backward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "es_point_backward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "es_wgrad_scratch_floats": (C.c_int64, []),

@@ -27,6 +27,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st, const void* packed_x3 = nullptr);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
 size_t wgrad_det_floats();
+int gemm_atb(const float* X, const float* dA, int M, float* out, int x3, float* det, hipStream_t st);
 int train_loss(const LossArgs& a, hipStream_t st);
 int train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
                      float* x, float* t, unsigned char* valid, hipStream_t st);
@@ -263,6 +264,10 @@ int es_point_backward(const es_points* pts, const float* packed, const float* we
     return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, nullptr, (hipStream_t)stream);
 }
 int64_t es_wgrad_scratch_floats(void) { return (int64_t)wgrad_det_floats(); }
+int es_gemm_atb(const float* X, const float* dA, int M, float* out, int split_precision, float* wg_scratch, void* stream) {
+    ES_REQUIRE(X && dA && out && M > 0 && M % 64 == 0, "es_gemm_atb: X [M][256], dA [M][256], out [256][256], M a multiple of 64");
+    return gemm_atb(X, dA, M, out, split_precision, wg_scratch, (hipStream_t)stream);
+}
 int es_point_backward_det(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, float* wg_scratch, void* stream) {
     if (int e = check_src(pts)) return e;

@@ -740,6 +740,14 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
     return ST_OK;
 }
 size_t wgrad_det_floats() { return WG_DET_FLOATS; }
+// One bare GEMM of the weight-gradient kernels: out[n][k] += sum_m dA[m][n] X[m][k] for row-major X [M][256], dA [M][256], out [256][256]
+// (M a multiple of 64), on the fp32 matrix pipes (x3 = 0) or in split precision (x3 = 1: both operands split exactly into three bf16
+// planes, six partial products, fp32 accumulation).  The accuracy tests drive both with adversarial operands (tests/test_gpu_split_accuracy.py).
+int gemm_atb(const float* X, const float* dA, int M, float* out, int x3, float* det, hipStream_t st) {
+    WgProb g[1] = {WgProb{X, dA, out, nullptr, 256, 256, 256, M, 256, 256, 1, 0, 0, 0, 0}};
+    WgSmall sm[1];
+    return launch_group(g, 1, sm, 0, x3 ? KID_WGRAD_D_X3 : KID_WGRAD_D, M, det, x3 != 0, st);
+}
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
 // ``det`` (nullable): scratch of wgrad_det_floats() floats => deterministic reduction instead of fp32 atomics.
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st) {

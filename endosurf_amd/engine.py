@@ -334,11 +334,10 @@ class PointCtx:
         return v
 
 
-def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, like_save: bool = False) -> PointCtx:
-    """``like_save``: evaluate with the kernels a PF_SAVE call would run (the forward pass of a chunked, re-evaluated render)."""
+def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
     ctx = PointCtx(self, pts, flags, m_color)
     save = bool(flags & _lib.PF_SAVE)
-    if self.split_precision and not like_save and pts.M >= self.x3_infer_min and (self.x3_train_chain or not save):
+    if self.split_precision and pts.M >= self.x3_infer_min and (self.x3_train_chain or not save):
         # opt-in: the launches of a large evaluation in split precision -- csrc/infer_x3r.hip without PF_SAVE; with PF_SAVE the
         # split-precision TRAINING chain, whose workspace must go through es_point_backward_x3 (``ctx.x3_chain``)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))

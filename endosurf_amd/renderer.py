@@ -460,10 +460,10 @@ class _RenderFn(torch.autograd.Function):
                 r_, z_ = rays[i:i + chunk_rays], z[i:i + chunk_rays]
                 n_ = r_.shape[0]
                 mid = eng.mid_z(z_, sample_dist)
-                # same kernels as the re-evaluation in the backward (``like_save``): the loss adjoints are then taken at exactly
-                # the outputs the backward differentiates
-                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), weff, packed, (flags & ~_lib.PF_SAVE) | _lib.PF_COLOR,
-                                         like_save=True)
+                # the SAME launches as the re-evaluation in the backward (saving into a workspace that is dropped right away: one chunk's
+                # worth, what the backward will allocate anyway): the loss adjoints are then taken at exactly the outputs the backward
+                # differentiates, whichever kernel family the engine selects for a saving evaluation
+                pctx = eng.point_forward(eng.points(rays=r_, z=mid, n_per_ray=S, ldz=S), weff, packed, flags | _lib.PF_COLOR)
                 a = eng.composite_args(r_, z_, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
                 out = eng.composite_forward(a, eik_acc=eik_acc)
                 for k in ("color", "depth", "weights", "weight_max", "cdf", "wmax_idx"):

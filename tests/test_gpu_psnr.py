@@ -32,7 +32,7 @@ def _reference_runs():
     """Every committed run of the reference on this schedule: {name: curve}; the 4-thread run first."""
     import glob
     runs = {"psnr_reference_long": np.load(GOLD)["curve"]}
-    for f in sorted(glob.glob(os.path.join(GOLD_DIR, "psnr_reference_t*.npz"))):
+    for f in sorted(glob.glob(os.path.join(GOLD_DIR, "psnr_reference_t*.npz"))):       # (incomplete / differently scheduled runs are skipped below)
         c = np.load(f)["curve"]
         if len(c) == len(runs["psnr_reference_long"]):
             runs[os.path.basename(f)[:-4]] = c
@@ -46,12 +46,12 @@ def _plateau_band(runs):
     return float(np.mean(ends)) - tol, float(np.mean(ends)) + tol, ends
 
 
-def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False):
+def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False, lr=5e-4):
     from endosurf_amd.trainer import Trainer, cal_psnr
     r = renderer_for(weight_seed, "init", True)
     r.engine.deterministic = deterministic
     r.engine.split_precision = split
-    tr = Trainer(r, lr=5e-4, n_iter=n_iter, warm_up_end=max(n_iter // 10, 1), lr_alpha=0.05, fused=True)
+    tr = Trainer(r, lr=lr, n_iter=n_iter, warm_up_end=max(n_iter // 10, 1), lr_alpha=0.05, fused=True)
     sched = synth_scene.schedule(sched_seed, n_iter, n_rays)
     ev = {k: torch.from_numpy(v).cuda() for k, v in synth_scene.eval_batch().items()}
     eval_its = set(int(i) for i in eval_its)
@@ -122,3 +122,71 @@ def test_psnr_plateau_in_split_precision_mode():
     lo, hi, ends = _plateau_band(_reference_runs())
     end = float(np.mean(curve[-N_TAIL:, 1]))
     assert lo < end < hi, (end, lo, hi, ends)
+
+
+N_HIP_RUNS = 6
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="reference PSNR curve not generated (tools/psnr_reference.py)")
+def test_psnr_plateau_distribution_matches_the_references():
+    """Distributional form of "matched PSNR" (round 3): training is chaotic, so ONE run against a band cannot see a systematic loss of
+    2-3 dB.  Here N_HIP_RUNS runs of the HIP renderer in the BENCHMARKED mode (fp32 atomics in the weight-gradient epilogues: their
+    summation order differs from run to run, which is the same perturbation as another thread count is to the reference) are compared
+    with every committed run of the reference (tests/golden/psnr_reference_*.npz: 2, 3, 4, 5 and, when present, 1 and 6 intra-op threads):
+      * |mean plateau (HIP) - mean plateau (reference)| <= 2.5 sqrt(SE_HIP^2 + SE_ref^2)   (standard errors of the two means; 2.5 instead of
+        2 keeps the false-alarm rate of a correct implementation near 1 %; with 6 + 6 runs the tolerance is ~2.5 dB, a systematic loss of
+        that size would show, and tightens as reference runs are added),
+      * the HIP runs do not scatter more than the reference's do (sample standard deviation <= 2.5 x, an F-test at ~2 %),
+      * every HIP run starts on the reference's trajectory (< 0.02 dB at iteration 1, < 0.1 dB up to iteration 60)."""
+    g = np.load(GOLD)
+    n_iter, n_rays, ref_curve = int(g["n_iter"]), int(g["n_rays"]), g["curve"]
+    runs = _reference_runs()
+    ref_pl = np.array([float(np.mean(c[-N_TAIL:, 1])) for c in runs.values()])
+    hip_pl, curves = [], []
+    for _ in range(N_HIP_RUNS):
+        curve, _ = _train(n_iter, n_rays, int(g["weight_seed"]), int(g["sched_seed"]), ref_curve[:, 0], deterministic=False)
+        d = curve[:, 1] - ref_curve[:, 1]
+        assert abs(d[0]) < 0.02 and np.max(np.abs(d[ref_curve[:, 0] <= 60])) < 0.1, d[:8]
+        hip_pl.append(float(np.mean(curve[-N_TAIL:, 1])))
+        curves.append(curve)
+    hip_pl = np.array(hip_pl)
+    se = float(np.sqrt(hip_pl.var(ddof=1) / len(hip_pl) + ref_pl.var(ddof=1) / len(ref_pl)))
+    delta = float(hip_pl.mean() - ref_pl.mean())
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    import json
+    with open(os.path.join(out, "psnr_stats.json"), "w") as f:
+        json.dump(dict(reference_runs=list(runs), reference_plateaus=ref_pl.tolist(), hip_plateaus=hip_pl.tolist(), delta_mean_db=delta,
+                       standard_error_db=se, hip_std_db=float(hip_pl.std(ddof=1)), reference_std_db=float(ref_pl.std(ddof=1)), mode="fp32, atomic reductions"), f)
+    np.savez(os.path.join(out, "psnr_hip_runs.npz"), curves=np.array(curves))
+    assert abs(delta) <= 2.5 * se, (delta, se, hip_pl.tolist(), ref_pl.tolist())
+    assert hip_pl.std(ddof=1) <= 2.5 * ref_pl.std(ddof=1) + 0.25, (hip_pl.tolist(), ref_pl.tolist())
+    assert hip_pl.min() > ref_curve[0, 1] + 15.0
+
+
+LOW = sorted(__import__("glob").glob(os.path.join(GOLD_DIR, "psnr_lowchaos_t*.npz")))
+
+
+@pytest.mark.skipif(len(LOW) < 2, reason="low-chaos reference runs not generated (PSNR_LR_SCALE=0.25 tools/psnr_reference.py 600 ...)")
+def test_psnr_low_chaos_schedule_is_tight():
+    """The same scene with the learning rate / 4 and 600 iterations: the reference then agrees with ITSELF (other thread counts) to
+    < 0.1 dB up to iteration 140, ~0.3 dB up to 200 and 0.6-0.8 dB on the (still rising) end of the curve -- a schedule on which a tight
+    comparison means something.  The HIP renderer (atomic mode, as benchmarked) must follow the reference's mean curve within the
+    reference's own half-range + 0.1 dB (early) / + 0.3 dB (to iteration 200) / + 0.5 dB (end: mean of the last 4 evaluations)."""
+    refs = [np.load(f) for f in LOW]
+    n_iter, n_rays, lr_scale = int(refs[0]["n_iter"]), int(refs[0]["n_rays"]), float(refs[0]["lr_scale"])
+    assert all(int(r["n_iter"]) == n_iter and float(r["lr_scale"]) == lr_scale for r in refs)
+    rc = np.stack([r["curve"][:, 1] for r in refs])              # [runs, evaluations]
+    its = refs[0]["curve"][:, 0]
+    mean, half = rc.mean(0), 0.5 * (rc.max(0) - rc.min(0))
+    curve, _ = _train(n_iter, n_rays, int(refs[0]["weight_seed"]), int(refs[0]["sched_seed"]), its, deterministic=False, lr=5e-4 * lr_scale)
+    d = np.abs(curve[:, 1] - mean)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    np.savez(os.path.join(out, "psnr_hip_lowchaos.npz"), curve=curve, ref=rc, its=its)
+    early, mid = its <= 140, its <= 200
+    assert np.all(d[early] <= half[early] + 0.1), (its[early][d[early] > half[early] + 0.1], d[early].max())
+    assert np.all(d[mid] <= half[mid] + 0.3), d[mid].max()
+    end_ref = rc[:, -N_TAIL:].mean(1)
+    end = float(curve[-N_TAIL:, 1].mean())
+    assert abs(end - end_ref.mean()) <= 0.5 * (end_ref.max() - end_ref.min()) + 0.5, (end, end_ref.tolist())

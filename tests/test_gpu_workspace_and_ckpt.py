@@ -35,7 +35,8 @@ def test_chunked_render_matches_unchunked():
     for gb in (64.0, 64 * 64 * 110e3 / 1e9):  # plenty | room for ~64 rays x 64 samples only
         r = renderer_for(41, "trained", True)
         r.workspace_gb = gb
-        loss, ret = _render_loss(r, b["rays"], u)
+        r.engine.x3_infer_min = 1             # (split-precision mode, ES_SPLIT_BF16=1: the same kernel family for the 4 096-point chunks
+        loss, ret = _render_loss(r, b["rays"], u)       # as for the 20 480-point batch; no effect on the fp32 default)
         loss.backward()
         torch.cuda.synchronize()
         res.append((float(loss), {k: v.detach().clone() for k, v in ret.items()}, {k: p.grad.clone() for k, p in r.named_parameters()},
