@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--split-precision", action="store_true",
                     help="OPT-IN extra line, never the headline: large no-grad SDF queries and the weight-gradient GEMMs on the bf16 matrix "
                          "pipes with exact 3-way operand splitting (csrc/query_x3.hip, wgrad.hip); everything else stays fp32 MFMA")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode: the whole training step captured once in a hipGraph and replayed (Trainer.train_step_graph); the "
+                         "per-kernel timers then run on a few eager steps after the timed region")
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
@@ -308,11 +311,16 @@ def main():
                 out = parallel.gather_frame(out, H, 640)
             return out
         elif mode == "train":
-            trainer.update_learning_rate(i + 1)
-            trainer.train_step(batches[i % len(batches)], i + 1)
+            if use_graph:
+                trainer.train_step_graph(batches[i % len(batches)], i + 1)
+            else:
+                trainer.update_learning_rate(i + 1)
+                trainer.train_step(batches[i % len(batches)], i + 1)
         else:
             with torch.no_grad():
                 renderer(batches[i % len(batches)]["rays"], iter_step=i + 1)
+
+    use_graph = bool(args.graph) and mode == "train"
 
     def barrier():
         if dist_on:
@@ -343,7 +351,7 @@ def main():
     # the same step with ray marching's early exit (blocks of 32 proposals; tiles whose rays have all passed their first sign change
     # return at once; results bit-identical): data-dependent, reported as an extra
     extra = None
-    if mode == "train" and march_block and not args.headline_only:
+    if mode == "train" and march_block and not args.headline_only and not use_graph:      # (a captured step keeps the marching mode it was captured with)
         eng.march_block = march_block
         step(nxt)
         dte = timed(nxt + 1, args.steps)
@@ -352,6 +360,7 @@ def main():
                      note="results bit-identical to the headline step; on this synthetic init-weight scene every ray's first sign change "
                           "falls in the first block of 32 proposals (best case)")
         eng.march_block = 0
+    use_graph = False          # (events cannot be recorded inside a captured graph: the per-kernel timers run on eager steps)
     # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 records timers
     if mode == "frame":
         # per-kernel durations need eager launches (events cannot be recorded inside the captured graph): a few chunks, eagerly
@@ -417,6 +426,7 @@ def main():
                    config=dict(workload="BASELINE config %d: %s nets, %d rays x (%d+%d) samples per GPU, %s" % (
                        args.config, cfg["name"], n_rays, cfg["n_samples"], cfg["n_importance"], what),
                        baseline_config=args.config, use_deform=cfg["use_deform"], split_precision=bool(args.split_precision),
+                       whole_step_hipgraph=bool(args.graph) and mode == "train",
                        ray_marching="all 128 proposals of every ray (data independent, as the reference)" if mode == "train" else None,
                        with_early_exit=extra, rays_per_gpu=n_rays,
                        collective=("rccl all-reduce forced at world 1" if force_dist else (

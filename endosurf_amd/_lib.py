@@ -25,7 +25,7 @@ class es_composite_args(C.Structure):
                 + [("N", C.c_int), ("S", C.c_int), ("sample_dist", C.c_float), ("cos_anneal", C.c_float)]
                 + [(n, C.c_void_p) for n in ("color", "depth", "weights", "cdf", "weight_max", "eik_acc", "wmax_idx",
                                              "g_color", "g_depth", "g_weights", "g_cdf", "g_wmax", "g_gradients_o", "g_eik",
-                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc", "ray_part")])
+                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc", "ray_part", "cos_anneal_dev")])
 
 
 class es_render_args(C.Structure):
@@ -95,6 +95,8 @@ PROTOTYPES = {
     "es_render_backward": (_I, [C.POINTER(es_render_args), _P, _P, _P, _P]),
     "es_train_aux_points": (_I, [_P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P]),
     "es_adam_step": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_longlong, _P]),
+    "es_train_schedule": (_I, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, C.c_double, _P, _P]),
+    "es_adam_step_dev": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, _P, _P, C.c_longlong, _P]),
     "es_timing_enable": (_I, [_I]),
     "es_timing_drain": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "es_kernel_name": (C.c_char_p, [_I]),

@@ -31,6 +31,10 @@ int gemm_atb(const float* X, const float* dA, int M, float* out, int x3, float* 
 int train_loss(const LossArgs& a, hipStream_t st);
 int train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
                      float* x, float* t, unsigned char* valid, hipStream_t st);
+int train_schedule(double* state, double lr_init, double n_iter, double warm_up_end, double lr_alpha, double beta1, double beta2, float grad_scale,
+                   double anneal_end, float* scal, hipStream_t st);
+int adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps, const float* scal,
+                  const float* g_extra, long long extra_index, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps, float step_size,
               float bc2_sqrt, float grad_scale, const float* g_extra, long long extra_index, hipStream_t st);
 static_assert(sizeof(es_loss_args) == sizeof(LossArgs), "es_loss_args must mirror es::LossArgs");
@@ -298,6 +302,17 @@ int es_adam_step(float* params, const float* grad, float* exp_avg, float* exp_av
     ES_REQUIRE(g_extra == nullptr || (extra_index >= 0 && extra_index < n), "es_adam_step extra gradient index");
     return adam_step(params, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, g_extra, extra_index,
                      (hipStream_t)stream);
+}
+int es_train_schedule(double* state, double lr_init, double n_iter, double warm_up_end, double lr_alpha, double beta1, double beta2,
+                      float grad_scale, double anneal_end, float* scal, void* stream) {
+    ES_REQUIRE(state && scal && n_iter > warm_up_end && warm_up_end >= 0, "es_train_schedule arguments");
+    return train_schedule(state, lr_init, n_iter, warm_up_end, lr_alpha, beta1, beta2, grad_scale, anneal_end, scal, (hipStream_t)stream);
+}
+int es_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float beta1, float beta2, float eps,
+                     const float* scal, const float* g_extra, long long extra_index, void* stream) {
+    ES_REQUIRE(params && grad && exp_avg && exp_avg_sq && scal && n >= 0, "es_adam_step_dev buffers");
+    ES_REQUIRE(g_extra == nullptr || (extra_index >= 0 && extra_index < n), "es_adam_step_dev extra gradient index");
+    return adam_step_dev(params, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, scal, g_extra, extra_index, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -15,5 +15,7 @@ struct CompositeArgs {
     // deterministic mode (nullable): [N][2] floats; the batch sums (eik_acc / d_invs_acc) are then formed from per-ray partials
     // in a fixed order instead of with fp32 atomics
     float* ray_part;
+    // nullable: cos_anneal read from device memory instead (a captured training step changes it between replays)
+    const float* cos_anneal_dev;
 };
 }  // namespace es

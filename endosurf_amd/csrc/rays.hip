@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
     if (ray >= a.N) return;
     const RayGeom g = load_ray(a.rays, ray);
     const float inv_s = inv_s_from_variance(a.variance[0]);
-    const float r = a.cos_anneal;
+    const float r = a.cos_anneal_dev != nullptr ? a.cos_anneal_dev[0] : a.cos_anneal;
     const int S = a.S;
     const int nchunk = (S + 63) / 64;
     constexpr int CH = RAY_NMAX / 64;

@@ -139,7 +139,8 @@ class Engine:
             e = packs[bool(use_deform)] = (buf, ev, cur)
         elif e[2] != cur:
             cur.wait_event(e[1])
-            e[0].record_stream(cur)
+            if not torch.cuda.is_current_stream_capturing():
+                e[0].record_stream(cur)
         return e[0]
 
     def x3_buffers(self):
@@ -214,8 +215,12 @@ class Engine:
         N, S = z.shape
         a.rays, a.z, a.ldz = ptr(rays), ptr(z), S
         a.sdf, a.g_o, a.rgb, a.variance = ptr(sdf), ptr(g_o), ptr(rgb), ptr(variance)
-        a.N, a.S, a.sample_dist, a.cos_anneal = N, S, float(sample_dist), float(cos_anneal)
-        a._keep = [rays, z, sdf, g_o, rgb, variance]
+        a.N, a.S, a.sample_dist = N, S, float(sample_dist)
+        if torch.is_tensor(cos_anneal):          # device scalar (a captured training step updates it between replays)
+            a.cos_anneal, a.cos_anneal_dev = 0.0, ptr(cos_anneal)
+        else:
+            a.cos_anneal, a.cos_anneal_dev = float(cos_anneal), None
+        a._keep = [rays, z, sdf, g_o, rgb, variance, cos_anneal]
         if self.deterministic:
             part = self.empty(N, 2)
             a.ray_part = ptr(part)

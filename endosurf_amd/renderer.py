@@ -450,7 +450,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused outputs (weights, cdf, ...) arrive as None, not as zero-filled tensors
         var1 = variance.detach().reshape(1)
         ctx.eng, ctx.weff, ctx.packed, ctx.variance = eng, weff, packed, variance
-        ctx.geom = (rays, z, float(sample_dist), float(cos_anneal))
+        ctx.geom = (rays, z, float(sample_dist), cos_anneal if torch.is_tensor(cos_anneal) else float(cos_anneal))
         ctx.flags = flags
         if (flags & _lib.PF_SAVE) and 0 < chunk_rays < N:
             ctx.chunk_rays, ctx.pctx, ctx.n_aux = int(chunk_rays), None, 0
@@ -577,6 +577,11 @@ class EndoSurfRenderer(nn.Module):
 
     def save_checkpoint(self):
         return self.model.save_checkpoint()
+
+    def _cos_anneal(self, iter_step):
+        """The cos-anneal ratio of ``iter_step`` (a float), or the device scalar a captured training step reads it from."""
+        dev = getattr(self, "_cos_anneal_dev", None)
+        return dev if dev is not None else self.get_cos_anneal_ratio(iter_step)
 
     def get_cos_anneal_ratio(self, iter_step):
         if self.anneal_end == 0.0:
@@ -730,7 +735,7 @@ class EndoSurfRenderer(nn.Module):
         z = z_vals if z_vals is not None else self.sample_z(rays, iter_step, perturb_overwrite, u_perturb)
         sample_dist = 2.0 / self.n_samples
         ret = self.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist,
-                               cos_anneal_ratio=self.get_cos_anneal_ratio(iter_step), eval=eval, _rays=rays, _aux=aux_points)
+                               cos_anneal_ratio=self._cos_anneal(iter_step), eval=eval, _rays=rays, _aux=aux_points)
         n_samples = z.shape[1]
         extra = {"aux_sdf": ret["aux_sdf"], "aux_gradients_o": ret["aux_gradients_o"]} if aux_points is not None else {}
         return {
@@ -760,7 +765,7 @@ class EndoSurfRenderer(nn.Module):
             aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
         flags = self._flags(weff)
         color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go = _RenderFn.apply(
-            weff, packed, var, self.engine, _rays, z, float(sample_dist), float(cos_anneal_ratio), flags, aux_x, aux_t,
+            weff, packed, var, self.engine, _rays, z, float(sample_dist), cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), flags, aux_x, aux_t,
             self._chunk_rays(z.shape[0], z.shape[1], flags))
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)

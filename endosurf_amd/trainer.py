@@ -55,7 +55,8 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     aux_x, aux_t, valid_sn = renderer._train_aux_points(rays, depth_gt, mask_gt, d_i, surf_neig_rad, u_neigh)    # one launch
     eod_pts = aux_x[:N]
     main.wait_stream(side)
-    z.record_stream(main)
+    if not torch.cuda.is_current_stream_capturing():      # (a captured step owns its memory pool: nothing is recycled between replays)
+        z.record_stream(main)
     # (the split-precision training chain takes the auxiliary points in the same launches as well; evaluating them with the fp32
     # kernels on the side stream instead was measured and is no faster: a co-running launch breaks the whole-round fit of the main ones)
     ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
@@ -179,6 +180,7 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps)]
         self.step_count = 0
+        self.scalars_dev = None          # device [step_size, bc2_sqrt, grad_scale] of a captured step (set by Trainer.capture_graph)
         self._named = [(self.model._layout[k][0], p) for k, p in self.model.ordered_params()]
         self._var = self.model.deviation_network.variance
         self._var_off = int(self.model._layout["deviation_network.variance"][0])
@@ -215,6 +217,15 @@ class FlatAdam:
         self.step_count += 1
         pg = self.param_groups[0]
         b1, b2 = pg["betas"]
+        if self.scalars_dev is not None:      # captured step: (step_size, bc2_sqrt, grad_scale) live in device memory (Trainer.train_step_graph)
+            _lib.check(self.eng.lib.es_adam_step_dev(_lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                                     self.flat.numel(), b1, b2, pg["eps"], _lib.ptr(self.scalars_dev),
+                                                     _lib.ptr(gv) if gv is not None else None, self._var_off, self.eng.st()), "es_adam_step_dev")
+            if frozen:
+                with torch.no_grad():
+                    torch._foreach_copy_([p for p, _ in frozen], [v for _, v in frozen])
+            self.model._epoch += 1
+            return
         step_size = pg["lr"] / (1.0 - b1 ** self.step_count)
         bc2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
         _lib.check(self.eng.lib.es_adam_step(_lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
@@ -341,6 +352,86 @@ class Trainer:
         if "optimizer" in ckpt:
             self.optimizer.load_state_dict(ckpt["optimizer"])
         return int(ckpt.get("n_iter", 0)) + 1
+
+    # ---- whole-step hipGraph ("so the whole training step is graph-capturable") -----------------------------------
+    def train_step_graph(self, batch, global_step: int):
+        """``train_step`` with the whole step -- weight-norm packing, ray marching, sampling, render, loss, backward, Adam: ~150 launches
+        on two streams -- captured ONCE per batch shape in a hipGraph (torch.cuda.CUDAGraph) and replayed.  Everything that changes from
+        step to step lives in device memory: the batch (copied into static buffers), the step counters from which the first launch of the
+        step computes the learning rate, Adam's bias corrections and the cos-anneal ratio (es_train_schedule: the reference's
+        update_learning_rate / get_cos_anneal_ratio on the device), the random draws (torch's graph-safe generator).  The first two calls
+        run eagerly (lazy initialisation; they are ordinary training steps), the third captures.  Under data parallelism the graph ends
+        with the flat gradient; the all-reduce and the Adam launch follow it eagerly.  Returns the loss (a static device tensor)."""
+        with torch.cuda.device(self.renderer.device):
+            return self._train_step_graph(batch, global_step)
+
+    def _train_step_graph(self, batch, global_step: int):
+        r, opt = self.renderer, self.optimizer
+        if not isinstance(opt, FlatAdam) or self.loss_fn is not compute_loss_fused:
+            raise ValueError("train_step_graph needs the fused schedule and FlatAdam (the defaults)")
+        g = getattr(self, "_graph", None)
+        shape = tuple(batch["rays"].shape)
+        if g is None or g["shape"] != shape:
+            scal = r.engine.zeros(4)          # step_size, bc2_sqrt, grad_scale | cos_anneal: written by es_train_schedule inside the step
+            g = self._graph = dict(shape=shape, batch={k: torch.empty_like(v) for k, v in batch.items()}, scal=scal,
+                                   state=torch.zeros(2, device=r.device, dtype=torch.float64), next=None, eager=0, graph=None, loss=None)
+            opt.scalars_dev, r._cos_anneal_dev = scal, scal[3:]
+        world = 1
+        if self.data_parallel:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        for k, v in batch.items():
+            g["batch"][k].copy_(v, non_blocking=True)
+        t = opt.step_count + 1
+        if g["next"] != (global_step, t):      # the device-resident counters follow the host's (first call, a jump in the step number)
+            g["state"].copy_(torch.tensor([global_step - 1, t - 1], dtype=torch.float64))
+        g["next"] = (global_step + 1, t + 1)
+        pg = opt.param_groups[0]
+
+        def schedule():
+            from . import _lib
+            _lib.check(r.engine.lib.es_train_schedule(_lib.ptr(g["state"]), float(self.lr_init), float(self.n_iter), float(self.warm_up_end),
+                                                      float(self.lr_alpha), float(pg["betas"][0]), float(pg["betas"][1]), 1.0 / world,
+                                                      float(r.anneal_end), _lib.ptr(g["scal"]), r.engine.st()), "es_train_schedule")
+
+        def body():
+            schedule()
+            opt.zero_grad(set_to_none=True)
+            # (optional "u_perturb" / "u_neigh" entries of the batch replace the random draws: reproducible tests)
+            loss, _, _ = self.loss_fn(r, g["batch"], global_step, self.loss_weights, self.surf_neig_rad, g["batch"].get("u_perturb"),
+                                      g["batch"].get("u_neigh"))
+            loss.backward()
+            if self.data_parallel:
+                return loss.detach(), opt.flat_grad(include_variance=True)
+            opt.step()
+            return loss.detach(), None
+
+        def finish(flat):
+            if self.data_parallel:
+                from .parallel import allreduce_flat
+                allreduce_flat(flat, force=self.force_collective)
+                opt.step(grad=flat, variance_in_grad=True)
+
+        if g["graph"] is None and g["eager"] < 2:        # lazy initialisation outside a capture: two ordinary steps
+            g["eager"] += 1
+            loss, flat = body()
+            finish(flat)
+            return loss
+        if g["graph"] is None:
+            count = opt.step_count
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g["loss"], g["flat"] = body()
+            opt.step_count = count                         # capturing launches nothing: the step count advances with the replays
+            g["graph"] = graph
+        g["graph"].replay()
+        if self.data_parallel:
+            finish(g["flat"])                              # (opt.step advances the count itself)
+        else:
+            opt.step_count = t
+        r.model._epoch += 1                                # parameters changed behind Python's back: packed weights are stale
+        r.model._pack_cache = None
+        return g["loss"]
 
     def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
         self.optimizer.zero_grad(set_to_none=True)

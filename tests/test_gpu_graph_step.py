@@ -1,0 +1,67 @@
+"""Whole-step hipGraph (Trainer.train_step_graph): the captured training step -- weight-norm packing, ray marching + secant, sampling,
+render, loss, backward, Adam, with the learning-rate schedule / bias corrections / cos-anneal ratio computed on the device -- follows the
+eager trajectory."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import renderer_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(graph, n_steps, n_rays=256, anneal_end=50000):
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+    from oracle_util import RENDER_CFG
+    r = renderer_for(5, "trained", True, render_cfg=dict(RENDER_CFG, anneal_end=anneal_end))
+    r.engine.deterministic = True
+    tr = Trainer(r, lr=1e-3, n_iter=40, warm_up_end=4, lr_alpha=0.05)
+    sc = SyntheticScene("cuda", seed=77)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    losses = []
+    for it in range(1, n_steps + 1):
+        b = sc.batch(n_rays)
+        b["u_perturb"] = torch.rand(n_rays, 1, device="cuda", generator=gen)
+        b["u_neigh"] = torch.rand(n_rays, 3, device="cuda", generator=gen)
+        if graph:
+            losses.append(float(tr.train_step_graph(b, it)))
+        else:
+            tr.update_learning_rate(it)
+            u, un = b.pop("u_perturb"), b.pop("u_neigh")
+            losses.append(float(tr.train_step(b, it, u_perturb=u, u_neigh=un)[0]))
+    return np.array(losses), r.model._flat.detach().clone(), tr
+
+
+def test_graph_step_follows_the_eager_trajectory():
+    """8 steps through the warm-up and into the cosine decay (the schedule changes every step; anneal_end = 6 makes the cos-anneal ratio
+    move too): the first two calls run eagerly, the third captures, the rest replay."""
+    le, pe, _ = _run(False, 8, anneal_end=6)
+    lg, pg, tr = _run(True, 8, anneal_end=6)
+    assert tr._graph["graph"] is not None and tr.optimizer.step_count == 8
+    assert np.allclose(le, lg, rtol=2e-5, atol=1e-6), (le, lg)
+    assert float((pe - pg).abs().max()) <= 2e-5 * float(pe.abs().max()), float((pe - pg).abs().max())
+    assert float((pe - renderer_for(5, "trained", True).model._flat).abs().max()) > 1e-3           # and the parameters did move
+    # the device-side schedule against the host formulas it replaces
+    st = tr._graph["state"].cpu().numpy()
+    assert st[0] == 8 and st[1] == 8
+    from endosurf_amd.trainer import lr_factor
+    lr = 1e-3 * lr_factor(8, 40, 4, 0.05)
+    want = [lr / (1 - 0.9 ** 8), math.sqrt(1 - 0.999 ** 8), 1.0, 1.0]
+    assert np.allclose(tr._graph["scal"].cpu().numpy(), want, rtol=1e-6)
+
+
+def test_graph_step_random_draws_and_recapture_on_a_new_shape():
+    """Without supplied draws the captured step uses torch's graph-safe generator (new jitter at every replay: the loss keeps changing),
+    and a batch of another shape captures a second graph."""
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+    r = renderer_for(5, "trained", True)
+    tr = Trainer(r, lr=5e-4, n_iter=100, warm_up_end=10)
+    sc = SyntheticScene("cuda", seed=1)
+    b = sc.batch(256)
+    losses = [float(tr.train_step_graph(b, it)) for it in range(1, 7)]
+    assert len(set(np.round(losses, 6))) == 6 and all(np.isfinite(losses))
+    g0 = tr._graph["graph"]
+    tr.train_step_graph(sc.batch(128), 7)
+    assert tr._graph["graph"] is None and tr._graph["shape"] == (128, 9) and g0 is not None
