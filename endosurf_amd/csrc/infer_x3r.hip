@@ -17,7 +17,7 @@
 
 namespace es {
 
-constexpr int XI_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + (128 * XR_ENC_LD + 8 * 256 + 3 * 256 + 4) * 4;
+constexpr int XI_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + (128 * XR_ENC_LD + 8 * 256 + 3 * 256 + 4) * 4 + XR_TILE_BYTES;      // + the save tiles (RowTile)
 static_assert(XI_LDS_BYTES <= 160 * 1024, "LDS carve");
 
 // ---- value + tangent ------------------------------------------------------------------------------------------------------------
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
     __syncthreads();
     const size_t urow = (size_t)point * 2 + (tan ? 1 : 0);     // this lane's row of the 2-rows-per-point stacks
     const size_t rows2 = (size_t)Mp * 2;
+    const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, 2 * (n & 15) + (tan ? 1 : 0), hi, lane};
+    const size_t wrow0 = ((size_t)blockIdx.x * 64 + wave * 16) * 2;      // first of the wave's 32 consecutive rows
     if (SAVE) {
 #pragma unroll
         for (int k = 0; k < 32; k += 4) st4(U0 + urow * 64 + 32 * hi + k, erow[32 * hi + k], erow[32 * hi + k + 1], erow[32 * hi + k + 2], erow[32 * hi + k + 3]);
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
         const bool skip = l == 4;                          // IDR skip: input of layer 4 = [h(204) | enc(52)] (1/sqrt2 folded into W4)
         u32x4 mk = {0u, 0u, 0u, 0u};
         init(C, l);
-        float* Ul = U + ((size_t)(l - 1) * rows2 + urow) * 256 + 4 * hi;      // u_l = this GEMM's operand
-        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
+        float* Ul = U + ((size_t)(l - 1) * rows2 + wrow0) * 256;              // u_l = this GEMM's operand
+        gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, [&](int s, int j) -> float {
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float z = P[b][4 * q + i];
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
             const float h = m ? z : 0.f;
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
-        }, NoSide(), [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Ul, s, v); });
+        }, NoSide(), [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Ul, 256); });
         if (!tan && point < Mp) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
         copy8(P, C);
     }
@@ -190,8 +192,10 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     float* Rrow = R + (size_t)(live ? point : 0) * 256 + 4 * hi;       // + l Mp 256: r_l of this lane's point
     const size_t rstride = (size_t)Mp * 256;
     int lsave = 7;
-    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * rstride, s, v); };      // (Mp is a multiple of 128: every point of the block is a row)
-    gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
+    const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, n, hi, lane};
+    float* Rwave = R + ((size_t)blockIdx.x * 128 + wave * 32) * 256;       // the wave's 32 rows (Mp is a multiple of 128: all of them exist)
+    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Rwave + lsave * rstride, 256); };
+    gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], g[0], fmaf(w8L[256 + f], g[1], w8L[512 + f] * g[2]));
@@ -218,19 +222,19 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
         };
         lsave = l;
         if (l == 3) {                           // 204 outputs of layer 3: 14 k-steps (the rest is zero padding in DR3)
-            gemm_rs<14, 2, false, (SAVE ? 2 : 0)>(C, ws, val, NoSide(), rsink);
+            gemm_rs<14, 2, false, (SAVE ? 4 : 0)>(C, ws, val, NoSide(), rsink);
             if (SAVE) {                         // features 224 .. 255 of r_3 are zero like 204 .. 223
                 const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 st_kstep(Rrow + 3 * rstride, 14, z8); st_kstep(Rrow + 3 * rstride, 15, z8);
             }
-        } else gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, val, NoSide(), rsink);
+        } else gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, val, NoSide(), rsink);
         copy8(P, C);
     }
     // r_0 = mask_0 . (adjoint of h_0);  adjoint of the encoding += W_0^T r_0 (52 outputs: accumulator group 0 only)
     mk = masks[mrow];
     zero(C);
     lsave = 0;
-    gemm_rs<16, 1, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {
+    gemm_rs<16, 1, false, (SAVE ? 4 : 0)>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;
     }, NoSide(), rsink);
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
 // layer): every lane computes exactly the 8 operand elements of its half of a k-step.  The geometry features come back from the
 // row-major WS_FEAT as a side stream of the weight pipeline (direct loads with per-lane source addresses: 2 x 16 B per lane and k-step).
 constexpr int XC_FRING_BYTES = XR_RING * 4 * 2048;
-constexpr int XC_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XC_FRING_BYTES + (8 * 256 + 3 * 256 + 4) * 4;
+constexpr int XC_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XC_FRING_BYTES + (8 * 256 + 3 * 256 + 4) * 4 + XR_TILE_BYTES;      // + the save tiles (RowTile)
 constexpr int XC_K_0S = 0, XC_K_0F = 6, XC_K_4S = 6 + 16 + 48 + 16, XC_K_4F = XC_K_4S + 6;     // logical k-steps of CF0S, CF0F, CF4S, CF4F
 static_assert(xr_kg(35) == 6 && xr_kg(41) == 6 && XC_K_4F == 92, "colour stream layout");
 
@@ -553,18 +557,19 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     const size_t mrow = pl * 2 + hi;
     const size_t hstride = (size_t)Mp * 256;
     float* Hrow = CH + pl * 256 + 4 * hi;                     // + (l - 1) Mp 256: h_l of this lane's point
-    float* Irow = CIN + pl * 128 + 4 * hi;
+    const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, n, hi, lane};
+    const size_t wrow0 = (size_t)blockIdx.x * 128 + wave * 32;      // the wave's 32 rows (SAVE: whole blocks of workspace rows)
     init8(C, biasL, hi);
-    gemm_rs<6, 2, false, (SAVE ? 2 : 0)>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Irow, s, v); });
+    gemm_rs<6, 2, false, (SAVE ? 4 : 0)>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, CIN + wrow0 * 128, 128); });
     kb = ws.k;
     gemm_r<16, 2, true>(C, ws, feat_val, side);
     copy8(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
-        float* Hl = Hrow + (size_t)(l - 1) * hstride;
+        float* Hl = CH + (size_t)(l - 1) * hstride + wrow0 * 256;
         mk = u32x4{0u, 0u, 0u, 0u};
-        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Hl, s, v); });
+        gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Hl, 256); });
         if (SAVE) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
         if (l == 4) {       // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
             gemm_r<6>(C, ws, small_val, side);

@@ -19,7 +19,7 @@
 
 namespace es {
 
-constexpr int XT_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + (128 * XR_ENC_LD + 3 * 256 + 4) * 4;
+constexpr int XT_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + (128 * XR_ENC_LD + 3 * 256 + 4) * 4 + XR_TILE_BYTES;      // + the save tiles (RowTile)
 static_assert(XT_LDS_BYTES <= 160 * 1024, "LDS carve");
 
 __device__ __forceinline__ void zero8(f32x16 (&A)[8]) {
@@ -81,6 +81,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
     const size_t mrow = prow * 2 + hi;
     const size_t tstride = (size_t)Mp * 256;
     float* Trow = T + prow * 256 + 4 * hi;
+    const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, n, hi, lane};
+    float* Twave = T + ((size_t)blockIdx.x * 128 + wave * 32) * 256;
     f32x16 P[8], C[8];
     zero8(C);
     gemm_r<4>(C, ws, enc_val);
@@ -89,15 +91,15 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
     for (int l = 1; l <= 7; ++l) {
         const bool skip = l == 4;                          // IDR skip: input of layer 4 = [tau(204) | tau_0(52)] (1/sqrt2 folded into W4)
         const u32x4 mk = masks[((size_t)(l - 1) * Mp) * 2 + mrow];
-        float* Tl = Trow + (size_t)(l - 1) * tstride;      // tau_l = this GEMM's operand
+        float* Tl = Twave + (size_t)(l - 1) * tstride;     // tau_l = this GEMM's operand
         zero8(C);
-        gemm_rs<16, 2, false, 2>(C, ws, [&](int s, int j) -> float {
+        gemm_rs<16, 2, false, 4>(C, ws, [&](int s, int j) -> float {
             const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float h = mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;      // layer 3: mask bits of features >= 204 are 0
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
-        }, NoSide(), [&](int s, const float (&v)[8]) { st_kstep(Tl, s, v); });
+        }, NoSide(), [&](int s, const float (&v)[8]) { rt.put(s, v, Tl, 256); });
         copy8(P, C);
     }
     {   // tau_8 = mask_7 . (W_7 tau_7);  J gbar_o = gbar_o + W_8 tau_8
@@ -158,11 +160,13 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
     float* Arow = A + arow * 256 + 4 * hi;
     const size_t astride = rows2 * 256;
     int lsave = 7;
-    const auto asink = [&](int s, const float (&v)[8]) { st_kstep(Arow + lsave * astride, s, v); };
+    const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, 2 * (n & 15) + (tan ? 1 : 0), hi, lane};
+    float* Awave = A + ((size_t)blockIdx.x * 64 + wave * 16) * 2 * 256;       // the wave's 32 consecutive rows
+    const auto asink = [&](int s, const float (&v)[8]) { rt.put(s, v, Awave + lsave * astride, 256); };
     f32x16 P[8], C[8];
     // abar_7 = mask_7 . (W8^T abar_8)  ->  adjoint of h_6 = W_7^T abar_7
     zero8(C);
-    gemm_rs<16, 2, false, 2>(C, ws, [&](int s, int j) -> float {
+    gemm_rs<16, 2, false, 4>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], a8[0], fmaf(w8L[256 + f], a8[1], w8L[512 + f] * a8[2]));
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
         };                                                                   // encoding part carries no parameter gradient)
         lsave = l;
         if (l == 3) {
-            gemm_rs<14, 2, false, 2>(C, ws, val, NoSide(), asink);
+            gemm_rs<14, 2, false, 4>(C, ws, val, NoSide(), asink);
             const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             st_kstep(Arow + 3 * astride, 14, z8); st_kstep(Arow + 3 * astride, 15, z8);
-        } else gemm_rs<16, 2, false, 2>(C, ws, val, NoSide(), asink);
+        } else gemm_rs<16, 2, false, 4>(C, ws, val, NoSide(), asink);
         copy8(P, C);
     }
     // abar_0 = mask_0 . (W_1^T abar_1): no further GEMM (the adjoint of the encoding input has no parameter gradient)

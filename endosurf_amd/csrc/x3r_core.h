@@ -261,6 +261,33 @@ __device__ __forceinline__ void st_kstep(float* row_hi, int s, const float (&v)[
     st4(row_hi + 16 * s + 8, v[4], v[5], v[6], v[7]);
 }
 
+// Coalescing sink of the training kernels' saved stacks.  A lane owns a ROW of a row-major [rows][ld] stack and gets 16 of its columns per
+// k-step (two 16-B pieces, the other lane half's between them): stored directly, every instruction touches 64 different cache lines with
+// 16 B each.  Instead the operands of a k-step PAIR (32 rows x 32 columns of the wave = one full 128-B line per row) are collected in an
+// LDS tile of the wave and written out as four stores of 8 complete lines each (lane -> row 8 i + lane / 8, 16-B chunk lane % 8).  Same
+// wave writes and reads the tile: LDS operations of a wave execute in order, no barrier.  The flush runs in the sink of the pair's odd
+// operand = at the end of an EVEN k-step, so its four stores are the youngest memory operations at the next barrier (gemm_rs NST = 4).
+constexpr int XR_TILE_LD = 36;                                   // floats per tile row (16-B aligned, shifts consecutive rows by 4 banks)
+constexpr int XR_TILE_BYTES = 4 * 32 * XR_TILE_LD * 4;            // one tile per wave
+struct RowTile {
+    float* t;           // this wave's tile [32][XR_TILE_LD]
+    int rowidx;         // this lane's row among the wave's 32 consecutive stack rows
+    int hi, lane;
+    __device__ __forceinline__ void put(int s, const float (&v)[8], float* wave_base, int ld) const {      // wave_base = &stack[first row of the wave][0]
+        float* p = t + rowidx * XR_TILE_LD + 16 * (s & 1) + 4 * hi;
+        *reinterpret_cast<v4f_frag*>(p) = v4f_frag{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<v4f_frag*>(p + 8) = v4f_frag{v[4], v[5], v[6], v[7]};
+        if (s & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+                const v4f_frag x = *reinterpret_cast<const v4f_frag*>(t + r * XR_TILE_LD + c);
+                *reinterpret_cast<v4f_frag*>(wave_base + (size_t)r * ld + 32 * (s >> 1) + c) = x;
+            }
+        }
+    }
+};
+
 // mask bit of register r of feature block b inside the 128-bit word of a (layer, point, lane half)
 __device__ __forceinline__ void mask_set(u32x4& mk, int b, int r, bool m) { mk[b >> 1] |= (m ? 1u : 0u) << ((b & 1) * 16 + r); }
 __device__ __forceinline__ bool mask_get(const u32x4& mk, int b, int r) { return (mk[b >> 1] >> ((b & 1) * 16 + r)) & 1u; }
