@@ -36,7 +36,18 @@ LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<5, 1>": "k_deform_f
            "k_query_sdf_x3r<true>": "k_query_sdf_x3", "k_query_sdf_x3r<false>": "k_query_sdf_x3", "k_deform_jvp_x3r": "k_deform_fwd_x3",
            "k_deform_vjp_x3r": "k_deform_vjp_x3", "k_sdf_fwd_x3r<true, true>": "k_sdf_fwd_x3", "k_sdf_fwd_x3r<true, false>": "k_sdf_fwd_x3",
            "k_sdf_fwd_x3r<false, true>": "k_sdf_fwd_x3", "k_sdf_fwd_x3r<false, false>": "k_sdf_fwd_x3", "k_color_fwd_x3r<true>": "k_color_fwd_x3",
-           "k_color_fwd_x3r<false>": "k_color_fwd_x3"}
+           "k_color_fwd_x3r<false>": "k_color_fwd_x3",
+           # round 3: the training chain of the family (SAVE instantiations of the above + csrc/train_x3r.hip)
+           "k_deform_jvp_x3r<true>": "k_deform_fwd_x3", "k_deform_jvp_x3r<false>": "k_deform_fwd_x3", "k_deform_vjp_x3r<true>": "k_deform_vjp_x3",
+           "k_deform_vjp_x3r<false>": "k_deform_vjp_x3", "k_color_fwd_x3r<true, true>": "k_color_fwd_x3", "k_color_fwd_x3r<true, false>": "k_color_fwd_x3",
+           "k_color_fwd_x3r<false, true>": "k_color_fwd_x3", "k_color_fwd_x3r<false, false>": "k_color_fwd_x3", "k_deform_tan_x3r": "k_deform_tan_x3",
+           "k_deform_bwd_x3r": "k_deform_bwd_x3", "k_color_bwd_x3r<true>": "k_color_bwd_x3", "k_color_bwd_x3r<false>": "k_color_bwd_x3",
+           "k_sdf_tan_x3r": "k_sdf_bwd_x3", "k_sdf_rev_x3r<true>": "k_sdf_bwd_x3", "k_sdf_rev_x3r<false>": "k_sdf_bwd_x3",
+           "k_wgrad_x3<0, false>": "k_wgrad_x3[deform]", "k_wgrad_x3<1, false>": "k_wgrad_x3[sdf]", "k_wgrad_x3<2, false>": "k_wgrad_x3[color]"}
+for _d in (True, False):
+    for _c in (True, False):
+        for _s in (True, False):
+            LOGICAL["k_sdf_fwd_x3r<%s, %s, %s>" % tuple(str(v).lower() for v in (_d, _c, _s))] = "k_sdf_fwd_x3"
 a, f, w = agg(d_sq), agg(d_f), agg(d_w)
 out = []
 for key in sorted(a, key=lambda k: -sum(a[k].get("GRBM_GUI_ACTIVE", [0]))):
