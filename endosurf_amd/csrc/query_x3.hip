@@ -102,7 +102,7 @@ __device__ long long x3_prof[512];
 #define X3_STAMP(i) do {} while (0)
 #endif
 template <bool DEFORM, int PTS>
-__global__ __launch_bounds__(X3Cfg<PTS>::THREADS, 1) void k_query_sdf_x3(PointSrc src, Tabs tb, X3Tabs xt, const u32x4* __restrict__ packed,
+__global__ __launch_bounds__(X3Cfg<PTS>::THREADS, (PTS == 32 ? 2 : 1)) void k_query_sdf_x3(PointSrc src, Tabs tb, X3Tabs xt, const u32x4* __restrict__ packed,
                                                                        const float* __restrict__ weff, float* __restrict__ sdf_out, int ld_out,
                                                                        const int* __restrict__ ray_done) {
     using Cfg = X3Cfg<PTS>;
@@ -238,6 +238,7 @@ size_t packed_x3r_bytes();
 int pack_x3r(const float* weff, void* packed, int use_deform, hipStream_t st);
 int query_sdf_x3r(const PointSrc& src, const void* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
                   const int* ray_done);
+constexpr int X3_SMALL_MAX = 8192;      // batches up to here run the 32-point LDS-resident tiles
 static bool use_x3r() {
 #ifdef ES_DEV_SWITCHES      // dev builds only: ES_X3R=0 selects the LDS-resident kernel of this file (A/B measurements)
     static const bool v = [] { const char* e = getenv("ES_X3R"); return !(e && e[0] == '0'); }();
@@ -261,25 +262,40 @@ int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st) 
     }
     a.off[X3_COUNT] = (unsigned)X3_UNITS;
     const unsigned n = (unsigned)(X3_UNITS / 3);
-    if (!use_x3r()) {       // the LDS-resident kernel's fragment order is only needed for A/B runs (ES_X3R=0)
-        hipLaunchKernelGGL(k_pack_x3, dim3((n + 255) / 256), dim3(256), 0, st, weff, reinterpret_cast<u32x4*>(packed_x3), a, use_deform ? 0 : 1);
-        if (int e = hip_last("pack_x3")) return e;
-    }
+    // the LDS-resident kernel's fragment order: small batches (32-point tiles, below) and the A/B runs of dev builds (ES_X3R=0)
+    hipLaunchKernelGGL(k_pack_x3, dim3((n + 255) / 256), dim3(256), 0, st, weff, reinterpret_cast<u32x4*>(packed_x3), a, use_deform ? 0 : 1);
+    if (int e = hip_last("pack_x3")) return e;
     return pack_x3r(weff, static_cast<unsigned char*>(packed_x3) + X3_UNITS * 16, use_deform, st);
 }
 
 int query_sdf_x3(const PointSrc& src, const void* packed_x3, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
                  const int* ray_done) {
-    if (use_x3r()) return query_sdf_x3r(src, static_cast<const unsigned char*>(packed_x3) + X3_UNITS * 16, weff, sdf_out, use_deform, st, ld_out, ray_done);
-    constexpr int PTS = X3_PTS;
-    using Cfg = X3Cfg<PTS>;
     static DeviceOnce attr_done;
     if (attr_done.first()) {
-        if (int e = allow_big_lds(k_query_sdf_x3<true, PTS>, Cfg::LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_query_sdf_x3<false, PTS>, Cfg::LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<true, 64>, X3Cfg<64>::LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<false, 64>, X3Cfg<64>::LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<true, 32>, X3Cfg<32>::LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_query_sdf_x3<false, 32>, X3Cfg<32>::LDS_BYTES)) return e;
         attr_done.done();
     }
     if (src.M <= 0) return ST_OK;
+    // Small batches (the 8 192-point up-sampling queries of a training step): the register-resident kernel's 128-point blocks would
+    // leave most of the chip idle (64 blocks) for the latency of a whole 17-layer chain; the LDS-resident formulation with 32-point tiles
+    // (4 waves, 62 KB of LDS: two workgroups per CU) spreads them over 256 workgroups.  Same arithmetic, same tests.
+    if (src.M <= X3_SMALL_MAX && ld_out == 0 && ray_done == nullptr) {
+        using Cfg = X3Cfg<32>;
+        const Tabs tb = make_tabs();
+        const X3Tabs xt = make_x3_tabs();
+        const dim3 grid((src.M + 31) / 32), block(Cfg::THREADS);
+        const u32x4* pk = reinterpret_cast<const u32x4*>(packed_x3);
+        ScopedTimer tm(KID_QUERY_X3, src.M, st);
+        if (use_deform) hipLaunchKernelGGL((k_query_sdf_x3<true, 32>), grid, block, Cfg::LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
+        else hipLaunchKernelGGL((k_query_sdf_x3<false, 32>), grid, block, Cfg::LDS_BYTES, st, src, tb, xt, pk, weff, sdf_out, ld_out, ray_done);
+        return hip_last("query_sdf_x3[32]");
+    }
+    if (use_x3r()) return query_sdf_x3r(src, static_cast<const unsigned char*>(packed_x3) + X3_UNITS * 16, weff, sdf_out, use_deform, st, ld_out, ray_done);
+    constexpr int PTS = 64;
+    using Cfg = X3Cfg<PTS>;
     const Tabs tb = make_tabs();
     const X3Tabs xt = make_x3_tabs();
     const dim3 grid((src.M + PTS - 1) / PTS), block(Cfg::THREADS);

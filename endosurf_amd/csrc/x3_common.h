@@ -41,11 +41,11 @@ __device__ __forceinline__ float softplus100_native(float z) {
 // cover its own operand latencies) -> 2.43 ms.  Requesting the bias values before the GEMM and a rolled (truly prefetching) weight
 // pipeline change nothing (the partner wave already hides those latencies); softplus' exp / log are 0.2 of the 1.9 ms.
 #ifndef X3_WAVES
-#define X3_WAVES (X3_PTS == 64 ? 8 : 4)
+#define X3_WAVES 8
 #endif
 template <int PTS>
 struct X3Cfg {
-    static constexpr int WAVES = X3_WAVES;              // PTS = 64: 8 or 16;  PTS = 32: 4
+    static constexpr int WAVES = PTS == 64 ? X3_WAVES : 4;      // PTS = 64: 8 (or 16);  PTS = 32: 4
     static constexpr int BLOCKS = 8 * (PTS / 32) / WAVES;   // 32 x 32 output blocks per wave
     static constexpr int PB = BLOCKS >= 2 && PTS == 64 ? 2 : 1;     // point blocks of a wave tile
     static constexpr int FB = BLOCKS / PB;                          // feature blocks of a wave tile

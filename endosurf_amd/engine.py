@@ -46,6 +46,7 @@ class Engine:
         # NOT the default; also settable per renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
         self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
         self._x3 = None
+        self.x3_query_min = int(os.environ.get("ES_X3_QUERY_MIN", "8193"))
         self.x3_infer_min = 16384      # points: below this a launch of 64/128-point tiles does not fill the chip
         # split-precision mode: grad-enabled evaluations run the split-precision TRAINING chain (infer_x3r.hip with saves +
         # train_x3r.hip); False keeps the fp32 chain kernels under the split-precision queries / weight gradients (round-2 behaviour)
@@ -148,7 +149,10 @@ class Engine:
         return [] if self._x3 is None else [self._x3["src"]] + [e[0] for e in self._x3["packs"].values()]
 
     def _use_x3(self, M: int) -> bool:
-        return self.split_precision and M > 8192          # small batches are latency-bound: they stay on the 16-point fp32 tiles
+        # small batches (the 1024-point secant queries, the 8 192-point up-sampling queries) are latency-bound chains: they stay on the
+        # 16-point fp32 tiles.  The library's split-precision query runs 32-point LDS-resident tiles up to 8 192 points, measured SLOWER
+        # there (0.27 vs 0.21 ms at 8 192 points, 0.27 vs 0.17 at 1 024: DESIGN 4, round 3), so the threshold stays above them
+        return self.split_precision and M >= self.x3_query_min
 
     def query_sdf(self, pts: es_points, weff, packed, use_deform: bool) -> torch.Tensor:
         out = self.empty(pts.M)

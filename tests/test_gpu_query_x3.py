@@ -64,7 +64,8 @@ def test_query_sdf_x3_ray_samples_golden():
     done[: (N // 2) // 2 * 2] = 1                      # rays of whole 64-point tiles (2 rays x 32 samples) are skipped
     got2 = _query_x3(lib, _lib, weff, True, ld_out=2 * n, ray_done=done, out=out, rays=rays, z=z, mode=1, n_per_ray=n, ldz=n, M=N * n)
     k = int(done.sum())
-    assert torch.all(got2[:k] == 0) and np.max(np.abs(got2[k:, :n].numpy() - got.numpy()[k:])) == 0 and torch.all(got2[:, n:] == 0)
+    # (the flat small-batch call above runs the 32-point tiles, the strided one the 128-point blocks: same arithmetic, other summation order)
+    assert torch.all(got2[:k] == 0) and np.max(np.abs(got2[k:, :n].numpy() - got.numpy()[k:])) < 2e-6 and torch.all(got2[:, n:] == 0)
 
 
 def test_split_precision_training_step_matches_fp32():
