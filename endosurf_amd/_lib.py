@@ -36,7 +36,8 @@ class es_loss_args(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("color_map", "depth_map", "eik", "aux_sdf", "aux_go", "rays", "eod_pts", "color_gt", "depth_gt",
                                             "mask", "cmask", "valid_sn")]
                 + [("N", C.c_int)] + [(n, C.c_float) for n in ("w_color", "w_depth", "w_sdf", "w_angle", "w_eik", "w_sn")]
-                + [(n, C.c_void_p) for n in ("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go")])
+                + [(n, C.c_void_p) for n in ("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go", "den_out", "den_global")]
+                + [("world", C.c_float)])
 
 
 _P = C.c_void_p

@@ -286,7 +286,8 @@ int es_point_backward_det(const es_points* pts, const float* packed, const float
 int es_train_loss(const es_loss_args* a, void* stream) {
     ES_REQUIRE(a && a->color_map && a->depth_map && a->eik && a->aux_sdf && a->aux_go && a->rays && a->eod_pts && a->color_gt &&
                a->depth_gt && a->mask && a->cmask && a->valid_sn, "es_train_loss inputs");
-    ES_REQUIRE(a->terms && a->g_color && a->g_depth && a->g_eik && a->g_aux_sdf && a->g_aux_go, "es_train_loss outputs");
+    ES_REQUIRE(a->den_out || (a->terms && a->g_color && a->g_depth && a->g_eik && a->g_aux_sdf && a->g_aux_go), "es_train_loss outputs");
+    ES_REQUIRE(!a->den_global || a->world >= 1.f, "es_train_loss: den_global needs the world size");
     return train_loss(*reinterpret_cast<const LossArgs*>(a), (hipStream_t)stream);
 }
 

@@ -57,11 +57,18 @@ __global__ __launch_bounds__(1024) void k_train_loss(LossArgs a) {
         sums[tid] = v;
     }
     __syncthreads();
-    const float den_c = sums[1] + 1e-10f, den_i = sums[3] + 1e-6f, den_d = sums[6] + 1e-10f;
-    const float den_sn = fmaxf(3.f * sums[8], 1.f);
+    if (a.den_out != nullptr) {      // the local normalisers only (exact data-parallel mode, first of two launches)
+        if (tid == 0) { a.den_out[0] = sums[1]; a.den_out[1] = sums[3]; a.den_out[2] = sums[6]; a.den_out[3] = sums[8]; }
+        return;
+    }
+    const bool glob = a.den_global != nullptr;
+    const float ws = glob ? a.world : 1.f;           // folded into the normalisers: term = world * sum / (global denominator)
+    const float den_c = ((glob ? a.den_global[0] : sums[1]) + 1e-10f) / ws, den_i = ((glob ? a.den_global[1] : sums[3]) + 1e-6f) / ws,
+                den_d = ((glob ? a.den_global[2] : sums[6]) + 1e-10f) / ws;
+    const float den_sn = fmaxf(3.f * (glob ? a.den_global[3] : sums[8]), 1.f) / ws;
     if (tid == 0) {
         const float lc = sums[0] / den_c, ls = sums[2] / den_i, la = sums[4] / den_i, ld = sums[5] / den_d, lsn = sums[7] / den_sn;
-        const float le = a.eik[0];
+        const float le = a.eik[0];                   // (exact mode: the caller has rescaled the eikonal term the same way)
         a.terms[0] = lc; a.terms[1] = ld; a.terms[2] = ls; a.terms[3] = la; a.terms[4] = le; a.terms[5] = lsn;
         a.terms[6] = a.w_color * lc + a.w_depth * ld + a.w_sdf * ls + a.w_angle * la + a.w_eik * le + a.w_sn * lsn;
         a.terms[7] = sums[8];

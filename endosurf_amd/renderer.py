@@ -471,6 +471,7 @@ class _RenderFn(torch.autograd.Function):
                 outs["go"].append(pctx.view("go")[:n_ * S].view(n_, S, 3).clone())
             cat = {k: torch.cat(v, 0) for k, v in outs.items()}
             ctx.eik_den = (eik_acc[1] + 1e-6).reshape(1)
+            eng.last_eik_den = ctx.eik_den
             eik = eik_acc[0] / ctx.eik_den[0]
             ctx.mark_non_differentiable(cat["wmax_idx"])
             return (cat["color"], cat["depth"], cat["go"], eik, cat["weights"], cat["weight_max"], cat["cdf"], cat["wmax_idx"],
@@ -484,6 +485,7 @@ class _RenderFn(torch.autograd.Function):
         a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
         out = eng.composite_forward(a)
         eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
+        eng.last_eik_den = eik_den          # the eikonal term's normaliser of the last render (exact data-parallel mode reads it)
         eik = out["eik_acc"][0] / eik_den[0]
         ctx.pctx, ctx.eik_den = pctx, eik_den
         ctx.n_aux = aux_x.shape[0] if fused else 0

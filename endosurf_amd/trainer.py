@@ -32,7 +32,7 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
 
 
 def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                       u_perturb=None, u_neigh=None, loss_kernel: bool = True):
+                       u_perturb=None, u_neigh=None, loss_kernel: bool = True, exact: bool = False):
     """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
     inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
     rays = renderer._rays32(batch["rays"])
@@ -62,8 +62,26 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     ret = renderer(rays, iter_step=iter_step, aux_points=(aux_x, aux_t), z_vals=z)
     a_sdf, a_go = ret["aux_sdf"], ret["aux_gradients_o"]
     if loss_kernel:
-        total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], ret["gradient_o_error"], a_sdf, a_go, renderer.engine, rays, eod_pts,
-                                 color_gt, depth_gt, mask_gt, cmask, valid_sn, weights)
+        eik = ret["gradient_o_error"]
+        exact_args = None
+        if exact:
+            # EXACT big-batch normalisers under data parallelism: the <= 6 denominators of the loss (colour mask, inside-sphere
+            # mask for the sdf / angle terms, valid x mask for depth, valid surface hits, the eikonal term's relaxed-sphere count) are summed
+            # over the ranks BEFORE the backward -- one 20-byte all-reduce; appending them to the gradient bucket cannot work, the gradient
+            # depends on them through 1 / D_k per term -- and every term is scaled by the world size: the mean over the ranks of the
+            # per-rank gradients is then exactly the gradient of the concatenated batch.
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            den = renderer.engine.empty(5)
+            _LossFn.sums(renderer.engine, rays, eod_pts, mask_gt, cmask, valid_sn, den)
+            den_local_eik = renderer.engine.last_eik_den            # sum relax + 1e-6 of this rank's render
+            den[4:5].copy_(den_local_eik - 1e-6)
+            if world > 1:
+                dist.all_reduce(den)
+            eik = eik * (float(world) * den_local_eik[0] / (den[4] + 1e-6))
+            exact_args = (den, float(world))
+        total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], eik, a_sdf, a_go, renderer.engine, rays, eod_pts,
+                                 color_gt, depth_gt, mask_gt, cmask, valid_sn, weights, exact_args)
         return total, dict(color=t[0], depth=t[1], sdf=t[2], angle=t[3], eikonal=t[4], surf_neig=t[5]), ret
     color_loss = ((ret["color_map"] - color_gt) * cmask).abs().sum() / (cmask.sum() + 1e-10)
     sdf_loss, angle_loss, valid = renderer._eod_loss(rays, eod_pts, mask_gt, a_sdf[:N], a_go[:N])
@@ -80,7 +98,27 @@ class _LossFn(torch.autograd.Function):
     """All six loss terms + total and their gradients in one HIP launch (es_train_loss)."""
 
     @staticmethod
-    def forward(ctx, color_map, depth_map, eik, aux_sdf, aux_go, eng, rays, eod_pts, color_gt, depth_gt, mask, cmask, valid_sn, w):
+    @staticmethod
+    def sums(eng, rays, eod_pts, mask, cmask, valid_sn, out):
+        """This rank's normalisers {sum cmask, sum inside, sum valid x mask, n_valid} -> out[0:4] (first launch of the exact mode)."""
+        import ctypes as C
+        from . import _lib
+        N = rays.shape[0]
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        keep = [f(rays), f(eod_pts), f(mask), f(cmask), (valid_sn.view(torch.uint8) if valid_sn.dtype == torch.bool else valid_sn.to(torch.uint8)).contiguous()]
+        z3, z1 = eng.zeros(3 * N, 3), eng.zeros(3 * N, 1)
+        a = _lib.es_loss_args()
+        for name, t in zip(("rays", "eod_pts", "mask", "cmask", "valid_sn"), keep):
+            setattr(a, name, _lib.ptr(t))
+        # the first pass reads every input of the kernel: give it defined (zero) renderer outputs and targets
+        for name, t in (("color_map", z3), ("color_gt", z3), ("depth_map", z1), ("depth_gt", z1), ("aux_sdf", z1), ("aux_go", z3), ("eik", z1)):
+            setattr(a, name, _lib.ptr(t))
+        a.N = N
+        a.den_out = _lib.ptr(out)
+        _lib.check(eng.lib.es_train_loss(C.byref(a), eng.st()), "es_train_loss")
+
+    @staticmethod
+    def forward(ctx, color_map, depth_map, eik, aux_sdf, aux_go, eng, rays, eod_pts, color_gt, depth_gt, mask, cmask, valid_sn, w, exact=None):
         import ctypes as C
         from . import _lib
         N = rays.shape[0]
@@ -99,6 +137,8 @@ class _LossFn(torch.autograd.Function):
         a.w_color, a.w_depth, a.w_sdf, a.w_angle, a.w_eik, a.w_sn = (float(w[k]) for k in ("color", "depth", "sdf", "angle", "eikonal", "surf_neig"))
         for name, t in zip(("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go"), [terms] + grads):
             setattr(a, name, _lib.ptr(t))
+        if exact is not None:            # (global normalisers [4+], world): see compute_loss_fused
+            a.den_global, a.world = _lib.ptr(exact[0]), float(exact[1])
         _lib.check(eng.lib.es_train_loss(C.byref(a), eng.st()), "es_train_loss")
         ctx.set_materialize_grads(False)
         ctx.grads = grads
@@ -109,9 +149,9 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         if g_total is None:
-            return (None,) * 14
+            return (None,) * 15
         gc, gd, ge, gs, gg = torch._foreach_mul(ctx.grads, g_total)       # one multi-tensor launch
-        return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None)
+        return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None, None)
 
 
 def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
@@ -308,7 +348,7 @@ class Trainer:
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
                  loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
-                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False):
+                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False, exact_denominators: bool = False):
         self.renderer = renderer
         self.force_collective = bool(force_collective)      # issue the gradient all-reduce even at world size 1 (RCCL smoke test)
         groups = renderer.get_train_params()
@@ -328,6 +368,14 @@ class Trainer:
         # "fused": auxiliary points inside the render launches (default); "plain": the reference's call sequence
         schedule = schedule or ("fused" if fused else "plain")
         self.loss_fn = {"fused": compute_loss_fused, "plain": compute_loss}[schedule]
+        # data parallel: all-reduce the loss normalisers before the backward, so that N ranks x B rays train exactly like one rank with
+        # N x B rays (default: standard DDP semantics, per-rank ratios averaged)
+        self.exact_denominators = bool(exact_denominators)
+        if self.exact_denominators:
+            if schedule != "fused":
+                raise ValueError("exact_denominators needs the fused schedule")
+            import functools
+            self.loss_fn = functools.partial(compute_loss_fused, exact=True)
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)
@@ -368,7 +416,8 @@ class Trainer:
     def _train_step_graph(self, batch, global_step: int):
         r, opt = self.renderer, self.optimizer
         if not isinstance(opt, FlatAdam) or self.loss_fn is not compute_loss_fused:
-            raise ValueError("train_step_graph needs the fused schedule and FlatAdam (the defaults)")
+            raise ValueError("train_step_graph needs the fused schedule and FlatAdam (the defaults; exact_denominators puts a collective "
+                             "into the forward pass and is not captured)")
         g = getattr(self, "_graph", None)
         shape = tuple(batch["rays"].shape)
         if g is None or g["shape"] != shape:

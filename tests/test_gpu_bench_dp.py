@@ -181,3 +181,62 @@ def test_bench_more_ranks_than_gpus_fails_fast():
                          env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
     assert out.returncode != 0
     assert f"only {n - 1} GPU(s) visible" in out.stderr, out.stderr[-2000:]
+
+
+def test_exact_denominators_two_ranks_equal_one_big_batch():
+    """Trainer(exact_denominators=True): 2 ranks x 512 rays give, after the summing all-reduce and the 1/world scale, the gradient of ONE
+    rank with the 1024-ray batch (the <= 6 loss normalisers all-reduced before the backward) -- with masks that differ between
+    the halves, so that the standard per-rank ratios would NOT agree (also checked)."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["ES_REPO"]); sys.path.insert(0, os.path.join(os.environ["ES_REPO"], "tests"))
+import torch
+import torch.distributed as dist
+from endosurf_amd import parallel
+from endosurf_amd.trainer import Trainer, SyntheticScene
+from gpu_util import renderer_for
+rank, world, local = parallel.init_distributed("gloo")
+torch.cuda.set_device(0)
+N = 1024
+sc = SyntheticScene("cuda", seed=42)
+gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+b = sc.batch(N)
+b["mask"] = (torch.rand(N, 1, device="cuda", generator=gen) < 0.7).float()
+b["mask"][:N // 2] *= (torch.rand(N // 2, 1, device="cuda", generator=gen) < 0.4).float()        # the halves differ a lot
+b["color_mask"] = (torch.rand(N, 1, device="cuda", generator=gen) < 0.8).float()
+u, un = torch.rand(N, 1, device="cuda", generator=gen), torch.rand(N, 3, device="cuda", generator=gen)
+def grad(sl, exact, dp):
+    r = renderer_for(5, "trained", True)
+    r.engine.deterministic = True
+    tr = Trainer(r, data_parallel=dp, exact_denominators=exact)
+    tr.optimizer.zero_grad()
+    loss, _, _ = tr.loss_fn(r, {k: v[sl] for k, v in b.items()}, 2000, tr.loss_weights, tr.surf_neig_rad, u[sl], un[sl])
+    loss.backward()
+    g = tr.optimizer.flat_grad(include_variance=True).clone()
+    if dp:
+        g /= parallel.allreduce_flat(g)
+    return g, float(loss)
+half = slice(rank * N // 2, (rank + 1) * N // 2)
+g_exact, l_exact = grad(half, True, True)
+g_ddp, _ = grad(half, False, True)
+g_big, l_big = grad(slice(0, N), False, False)
+lsum = torch.tensor([l_exact], device="cuda"); dist.all_reduce(lsum)
+if rank == 0:
+    n = float(g_big.norm())
+    print(json.dumps(dict(rel_exact=float((g_exact - g_big).norm()) / n, rel_ddp=float((g_ddp - g_big).norm()) / n,
+                          loss_mean=float(lsum) / world, loss_big=l_big)))
+dist.destroy_process_group()
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "w.py")
+        open(script, "w").write(code)
+        env = dict(os.environ, ES_REPO=REPO)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), script]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rel_exact"] < 2e-5, d                      # the big batch's gradient to fp32 rounding
+    assert abs(d["loss_mean"] - d["loss_big"]) < 1e-5 * max(1.0, abs(d["loss_big"])), d
+    assert d["rel_ddp"] > 50 * d["rel_exact"], d          # the averaged per-rank ratios are a different (standard DDP) objective
