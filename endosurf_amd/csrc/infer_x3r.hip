@@ -14,6 +14,7 @@
 #include "tabs.h"
 #include "timing.h"
 #include "workspace.h"
+#include "point_fwd_bodies.h"
 
 namespace es {
 
@@ -24,9 +25,9 @@ static_assert(XI_LDS_BYTES <= 160 * 1024, "LDS carve");
 // SAVE (training): the layer inputs u_0 (encoding rows) and u_1 .. u_8 go to WS_D_U0 / WS_D_U, row 2 p = value, row 2 p + 1 = tangent
 // of point p, row-major -- the X operands of the weight-gradient GEMMs (wgrad.hip), same layout as point_fwd.hip's deform_fwd_tile.
 template <bool SAVE>
-__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
-                                                                float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks,
-                                                                float* __restrict__ U0, float* __restrict__ U, int Mp) {
+__device__ __forceinline__ void deform_jvp_x3r_body(const PointSrc& src, const Tabs& tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                    float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks,
+                                                    float* __restrict__ U0, float* __restrict__ U, int Mp, const int blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     float* encs = reinterpret_cast<float*>(ldsr + XR_RING * XR_CHUNK_BYTES);      // [128 columns][68]
     float* biasL = encs + 128 * XR_ENC_LD;                                         // [8 layers][256]
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const bool tan = n >= 16;                                 // tangent column of point (n & 15)
-    const int point = blockIdx.x * 64 + wave * 16 + (n & 15);
+    const int point = blk * 64 + wave * 16 + (n & 15);
     float* erow = encs + (wave * 32 + n) * XR_ENC_LD;
     float x[3], t, d[3];
     load_point(src, point, x, t, d);
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
     const size_t urow = (size_t)point * 2 + (tan ? 1 : 0);     // this lane's row of the 2-rows-per-point stacks
     const size_t rows2 = (size_t)Mp * 2;
     const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, 2 * (n & 15) + (tan ? 1 : 0), hi, lane};
-    const size_t wrow0 = ((size_t)blockIdx.x * 64 + wave * 16) * 2;      // first of the wave's 32 consecutive rows
+    const size_t wrow0 = ((size_t)blk * 64 + wave * 16) * 2;             // first of the wave's 32 consecutive rows
     if (SAVE) {
 #pragma unroll
         for (int k = 0; k < 32; k += 4) st4(U0 + urow * 64 + 32 * hi + k, erow[32 * hi + k], erow[32 * hi + k + 1], erow[32 * hi + k + 2], erow[32 * hi + k + 3]);
@@ -150,6 +151,31 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, 
             }
         }
     }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                                float* __restrict__ ws_xc, float* __restrict__ ws_v, u32x4* __restrict__ masks,
+                                                                float* __restrict__ U0, float* __restrict__ U, int Mp) {
+    deform_jvp_x3r_body<SAVE>(src, tb, chunks, weff, ws_xc, ws_v, masks, U0, U, Mp, (int)blockIdx.x);
+}
+// Training batch with a colour-less tail (the 3N auxiliary points of a training step behind the ray samples): the main batch fills the
+// chip in whole rounds of this family's blocks, so the tail's few blocks would add a nearly empty round to EVERY launch.  As in the fp32
+// family (point_fwd.hip) the tail's dependent SDF + VJP stages ride at the head of the launch with the most and shortest rounds -- this
+// one (4 rounds of 64-point blocks at 1024 rays x 64 samples) -- as fp32 tile bodies (blocks [0, n0): tiles t0 ..; their deformation
+// stage ran as a small fp32 launch before): the tail costs one short round here instead of one round of every kernel.
+__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_jvp_x3r_tail(FwdArgs fa, int n0, int t0, const u32x4* __restrict__ chunks,
+                                                                     u32x4* __restrict__ masks) {
+    if ((int)blockIdx.x < n0) {
+        // (taking the tail's deformation stage into this workgroup as well makes its ~1.0 ms the launch's critical path -- the main
+        // part needs 0.78 ms: measured 1.01 ms against 0.77 + 0.165 ms for the deformation stage as a launch of its own)
+        sdf_fwd_tile(fa, t0 + (int)blockIdx.x);
+        __syncthreads();
+        deform_vjp_tile(fa, t0 + (int)blockIdx.x);
+        return;
+    }
+    deform_jvp_x3r_body<true>(fa.src, fa.tb, chunks, fa.weff, fa.ws + fa.L.off[WS_XC], fa.ws + fa.L.off[WS_V], masks, fa.ws + fa.L.off[WS_D_U0],
+                              fa.ws + fa.L.off[WS_D_U], fa.L.Mp, (int)blockIdx.x - n0);
 }
 
 // ---- reverse sweep ---------------------------------------------------------------------------------------------------------------
@@ -614,6 +640,7 @@ static int infer_attrs() {
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_deform_jvp_x3r<false>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_jvp_x3r<true>, XI_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_jvp_x3r_tail, XI_LDS_BYTES > LEAN_LDS_BYTES ? XI_LDS_BYTES : LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<false>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<true>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true, false>, XS_LDS_BYTES)) return e;
@@ -647,11 +674,22 @@ int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
                             (float*)nullptr, (float*)nullptr, L.Mp);
     return hip_last("deform_jvp_x3r");
 }
-int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st) {
+// the training batch's main part [0, m_main) through this family's value + tangent kernel, its colour-less tail's SDF + VJP stages as fp32
+// tile bodies at the head of the same launch (k_deform_jvp_x3r_tail); m_main is a multiple of 128, the tail's deformation stage has run
+int deform_jvp_x3r_with_tail(const FwdArgs& fa, const void* packed_r, int m_main, hipStream_t st) {
+    if (int e = infer_attrs()) return e;
+    ScopedTimer tm(KID_DEFORM_FWD_X3, fa.src.M, st);
+    const int n0 = (fa.L.Mp - m_main) / TM;
+    hipLaunchKernelGGL(k_deform_jvp_x3r_tail, dim3(n0 + m_main / 64), dim3(XR_THREADS), XI_LDS_BYTES > LEAN_LDS_BYTES ? XI_LDS_BYTES : LEAN_LDS_BYTES, st, fa, n0,
+                       m_main / TM, reinterpret_cast<const u32x4*>(packed_r), reinterpret_cast<u32x4*>(fa.ws + fa.L.off[WS_D_MASK]));
+    return hip_last("deform_jvp_x3r_with_tail");
+}
+// m_rows: the points [0, m_rows) (a multiple of 128; default all workspace rows)
+int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st, int m_rows) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_DEFORM_VJP_X3, src.M, st);
-    const dim3 grid((L.Mp + 127) / 128), block(XR_THREADS);
+    ScopedTimer tm(KID_DEFORM_VJP_X3, m_rows > 0 ? m_rows : src.M, st);
+    const dim3 grid(((m_rows > 0 ? m_rows : L.Mp) + 127) / 128), block(XR_THREADS);
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
     const u32x4* mk = reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]);
     if (save) hipLaunchKernelGGL(k_deform_vjp_x3r<true>, grid, block, XI_LDS_BYTES, st, src, tb, pk, weff, ws + L.off[WS_GC], ws + L.off[WS_GO], mk,

@@ -13,494 +13,10 @@
 #include "tabs.h"
 #include "timing.h"
 #include "workspace.h"
+#include "point_fwd_bodies.h"
 
 namespace es {
 
-struct FwdArgs {
-    PointSrc src;
-    Tabs tb;
-    const float4* packed;
-    const float* weff;
-    float* ws;
-    WsLayout L;
-    int flags;
-    int M_color;       // points [0, M_color) go through the colour network (multiple of 64 unless == M)
-};
-
-__device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws + a.L.off[buf]; }
-
-// -------------------------------------------------------------------------------------------------------------
-// deformation network, value + forward-mode tangent along the ray direction d:  x_c = x + MLP(x, t) and v = J d.
-// Tile = 32 points = 64 rows (row 2p = value, row 2p + 1 = tangent).  The layer outputs u_1..u_8 are always streamed out:
-// their value rows are the ReLU masks of the VJP sweep below (inference writes only those rows).
-__device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;
-    float* scr = aux + AUX56_FLOATS;
-    float* px = scr;         // [3][32]
-    float* pd = scr + 96;    // [3][32] ray direction
-    float* pt = scr + 192;   // [32]
-    float* red = aux;        // [4][3][64]: the encoding rows are dead after layer 3's epilogue
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = tile * 32;
-    const size_t grow0 = (size_t)pt0 * 2;
-    const bool save = a.flags & PF_SAVE;
-    const size_t rows2 = (size_t)a.L.Mp * 2;
-
-    if (tid < 32) {
-        float x[3], t, d[3];
-        load_point(a.src, pt0 + tid, x, t, d);
-        px[tid] = x[0]; px[32 + tid] = x[1]; px[64 + tid] = x[2]; pt[tid] = t;
-        pd[tid] = d[0]; pd[32 + tid] = d[1]; pd[64 + tid] = d[2];
-    }
-    zero_rows(aux, 0, 56, tid);
-    __syncthreads();
-    {   // encoding rows: value row 2p, tangent row 2p+1 = (d enc / d x) d; the time part has no tangent
-        const int p = tid & 31;
-        for (int item = tid >> 5; item < 25; item += 8) {
-            if (item < 18) {
-                const int c = item % 3, i = item / 3;
-                const float f = (float)(1 << i);
-                float s, co;
-                sincosf(px[c * 32 + p] * f, &s, &co);
-                const float dc = pd[c * 32 + p];
-                aux[swz(enc_index(3, i, 0, c), 2 * p)] = s;
-                aux[swz(enc_index(3, i, 1, c), 2 * p)] = co;
-                aux[swz(enc_index(3, i, 0, c), 2 * p + 1)] = f * co * dc;
-                aux[swz(enc_index(3, i, 1, c), 2 * p + 1)] = -f * s * dc;
-            } else if (item < 24) {
-                const int i = item - 18;
-                float s, co;
-                sincosf(pt[p] * (float)(1 << i), &s, &co);
-                aux[swz(39 + enc_index(1, i, 0, 0), 2 * p)] = s;
-                aux[swz(39 + enc_index(1, i, 1, 0), 2 * p)] = co;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { aux[swz(c, 2 * p)] = px[c * 32 + p]; aux[swz(c, 2 * p + 1)] = pd[c * 32 + p]; }
-                aux[swz(39, 2 * p)] = pt[p];
-            }
-        }
-    }
-    __syncthreads();
-    if (save) {   // u_0 rows for the weight-gradient GEMM: [2Mp][64], 56 columns written
-        float* U0 = wsb(a, WS_D_U0);
-        const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 56; k += 4) U0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
-    }
-
-    float* U = wsb(a, WS_D_U);
-    unsigned* MK = reinterpret_cast<unsigned*>(wsb(a, WS_D_MASK));
-    const size_t nt32 = (size_t)a.L.Mp / 32;
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l];
-        float* Ul = U + (size_t)l * rows2 * 256;
-        unsigned bits = 0;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {       // rows: value, tangent, value, tangent
-            if (l == 3 && col >= 204) {
-                lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
-            } else {
-                const float b = bias[col];
-                const float a0 = v[0] + b, a2 = v[2] + b;
-                const bool m0 = a0 > 0.f, m2 = a2 > 0.f;         // the ReLU mask of a value row gates its tangent
-                v[0] = m0 ? a0 : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? a2 : 0.f; v[3] = m2 ? v[3] : 0.f;
-                bits |= (m0 ? 1u : 0u) << (2 * qi) | (m2 ? 1u : 0u) << (2 * qi + 1);
-            }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Ul, grow0, 256, row, col, v);
-        });
-        MK[((size_t)l * nt32 + tile) * 256 + tid] = bits;        // the masks of the VJP / tangent / reverse sweeps
-    };
-    {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
-        epi(acc, 0);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
-        __syncthreads();
-        epi(acc, l);
-        __syncthreads();
-    }
-    smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
-    __syncthreads();
-    if (tid < 192) {
-        const int i = tid >> 6, row = tid & 63, p = row >> 1, c = row & 1;
-        const float val = smalln_reduce<3>(red, i, row);
-        const size_t gp = (size_t)(pt0 + p);
-        if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 32 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
-        else wsb(a, WS_V)[gp * 3 + i] = val + pd[i * 32 + p];          // J d = d + (d Delta x / d x) d
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// deformation network, reverse (VJP) sweep for the covector g_c:  g_o = J^T g_c = g_c + E(x)^T W_0^T M_0 W_1^T ... M_7 W_8^T g_c
-// (get_sdf_grad_from_observed_space, endosurf.py:581-601, is exactly this product).  Tile = 64 points, one row per point;
-// masks M_l from the value rows of u_{l+1}.  With PF_SAVE the adjoints r_0..r_7 are kept: paired with the tangent sweep of
-// the backward pass they give this path's weight gradient.
-__device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;          // adjoint of the 52 encoding inputs (skip part + layer 0), rows 52..55 zero
-    float* scr = aux + AUX56_FLOATS;
-    float* g8 = scr;                         // [3][64] g_c
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = tile * TM;
-    const size_t grow0 = (size_t)row0;
-    const bool save = a.flags & PF_SAVE;
-    const size_t Mp = (size_t)a.L.Mp;
-    const unsigned* MK = reinterpret_cast<const unsigned*>(wsb(a, WS_D_MASK));
-    const size_t nt32 = Mp / 32;
-    const int hi = lane >> 5;
-    float* R = wsb(a, WS_D_R);
-
-    if (tid < 64) {
-        const float* gc = wsb(a, WS_GC) + (grow0 + tid) * 3;
-        g8[tid] = gc[0]; g8[64 + tid] = gc[1]; g8[128 + tid] = gc[2];
-    }
-    zero_rows(aux, 0, 56, tid);
-    __syncthreads();
-    {   // r_7 = mask_7 * (W8^T g_c)
-        const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
-        const MaskWords mk = load_mask_words(MK + (size_t)7 * nt32 * 256, tile, wave, lane);
-        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
-            const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
-            const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? g8[row + i] * w0 + g8[64 + row + i] * w1 + g8[128 + row + i] * w2 : 0.f;
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(R + (size_t)7 * Mp * 256, grow0, 256, row, col, v);
-        });
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 7; l >= 1; --l) {
-        const MaskWords mk = load_mask_words(MK + (size_t)(l - 1) * nt32 * 256, tile, wave, lane);     // in flight during the GEMM
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
-        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
-        __syncthreads();
-        float* Rl = R + (size_t)(l - 1) * Mp * 256;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            if (l == 4 && col >= 204) {
-                lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
-            }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Rl, grow0, 256, row, col, v);
-        });
-        __syncthreads();
-    }
-    {   // adjoint of the encoding input: += W_0^T r_0
-        f32x16 accA[1][1];
-        acc_zero(accA);
-        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[DR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 52) lds_add_quad(aux, col, row, v); });
-    }
-    __syncthreads();
-    if (tid < 192) {   // g_o[j] = g_c[j] + sum_k adj[k] * d enc_k / d x_j   (position part of the encoding, observed-space x)
-        const int j = tid >> 6, row = tid & 63;
-        float x[3], t, d[3];
-        load_point(a.src, row0 + row, x, t, d);
-        float g = g8[j * 64 + row] + aux[swz(j, row)];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float f = (float)(1 << i);
-            float s, co;
-            sincosf(x[j] * f, &s, &co);
-            g += f * (aux[swz(enc_index(3, i, 0, j), row)] * co - aux[swz(enc_index(3, i, 1, j), row)] * s);
-        }
-        wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// SDF network: value pass + reverse sweep.  Tile = 64 points.
-__device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* mainT = lds;
-    float* aux = lds + MAIN_FLOATS;        // 56 rows: enc6(x_c) (40 used), later the adjoint of the encoding (40 used)
-    float* scr = aux + AUX56_FLOATS;
-    float* px = scr;          // [3][64]
-    float* red = aux;         // [4][1][64]  (encoding rows are dead when the last layer runs)
-    float* gcv = mainT;       // [3][64]     (activation tile is dead after the last reverse GEMM)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = tile * TM;
-    const size_t grow0 = (size_t)row0;
-    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM, color = (a.flags & PF_COLOR) && row0 < a.M_color;
-    const size_t Mp = (size_t)a.L.Mp;
-
-    if (tid < 64) {
-        if (deform) {
-            const float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
-            px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
-        } else {
-            float x[3], t, d[3];
-            load_point(a.src, row0 + tid, x, t, d);
-            px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2];
-            float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
-            xc[0] = x[0]; xc[1] = x[1]; xc[2] = x[2];
-        }
-    }
-    __syncthreads();
-    encode3<6>(aux, 0, px, tid);
-    zero_rows(aux, 39, 40, tid);
-    __syncthreads();
-    if (save) {
-        float* S0 = wsb(a, WS_S_S0);
-        const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 40; k += 4) S0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
-    }
-    float* SACT = wsb(a, WS_S_ACT);
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + l];
-        float* Sl = SACT + (size_t)l * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            const float b = bias[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
-            lds_store_quad(mainT, col, row, v);
-            g_store_quad_f(Sl, grow0, row, col, v);
-        });
-    };
-    {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
-        epi(acc, 0);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
-        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
-        __syncthreads();
-        epi(acc, l);
-        __syncthreads();
-    }
-    // last layer: 256 geometry features (MFMA) + sdf (row 0, VALU)
-    if (color) {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[SF8F], 0, 2 * wave, lane);
-        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + 8] + 1;
-        float* feat = wsb(a, WS_FEAT);
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            const float b = bias[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += b;
-            g_store_quad(feat, grow0, 256, row, col, v);
-        });
-    }
-    smalln_partial<1>(mainT, a.weff + a.tb.woff[NET_S * LAYERS + 8], 256, red, tid);
-    __syncthreads();
-    if (tid < 64) wsb(a, WS_SDF)[grow0 + tid] = smalln_reduce<1>(red, 0, tid) + a.weff[a.tb.boff[NET_S * LAYERS + 8]];
-
-    // ---- reverse sweep: rho_l = d sdf / d z_l ----
-    float* RHO = wsb(a, WS_S_RHO);
-    {   // rho_7 = softplus'(z_7) * W8[0,:]   (mainT still holds s_8 = softplus(z_7))
-        const float* w8 = a.weff + a.tb.woff[NET_S * LAYERS + 8];
-        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
-            float v[4];
-            lds_load_quad(mainT, col, row, v);
-            const float w = w8[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(v[i]) * w;
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad_f(RHO + (size_t)7 * Mp * 256, grow0, row, col, v);
-        });
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 7; l >= 1; --l) {
-        const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);       // adjoint of s_l
-        f32x16 accA[1][1];
-        if (l == 4) {
-            acc_zero(accA);
-            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
-        }
-        float S[16][4];                                          // all 16 quads requested at once: one memory round trip
-        prefetch_quads_f<2, 2>(S, Sl, grow0, 0, 2 * wave, lane);
-        __syncthreads();
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad_f(RHO + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
-        });
-        if (l == 4)
-            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
-        __syncthreads();
-    }
-    {
-        f32x16 accA[1][1];
-        acc_zero(accA);
-        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_add_quad(aux, col, row, v); });
-    }
-    __syncthreads();
-    if (save) {
-        float* AE = wsb(a, WS_S_ADJEPS);
-        const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 40; k += 4) AE[(grow0 + r) * 64 + k] = aux[swz(k, r)];
-    }
-    if (tid < 192) {   // g_c[j] = sum_k adj_eps[k] * d enc_k / d x_j
-        const int j = tid >> 6, row = tid & 63;
-        const float x = px[j * 64 + row];
-        float g = aux[swz(j, row)];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float f = (float)(1 << i);
-            float s, co;
-            sincosf(x * f, &s, &co);
-            g += f * (aux[swz(enc_index(3, i, 0, j), row)] * co - aux[swz(enc_index(3, i, 1, j), row)] * s);
-        }
-        gcv[j * 64 + row] = g;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const size_t gp = grow0 + tid;
-        const float g0 = gcv[tid], g1 = gcv[64 + tid], g2 = gcv[128 + tid];
-        float* gc = wsb(a, WS_GC) + gp * 3;
-        gc[0] = g0; gc[1] = g1; gc[2] = g2;
-        if (!deform) {      // with a deformation network g_o = J^T g_c is the VJP sweep (deform_vjp_tile)
-            float* go = wsb(a, WS_GO) + gp * 3;
-            go[0] = g0; go[1] = g1; go[2] = g2;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// colour network.  Tile = 64 points.  Lean LDS carve (activation tile + 5 KB): the 93-wide small part of the input is
-// staged through the activation tile itself (and re-staged from HBM at the skip layer), so two workgroups fit per CU.
-constexpr int CFWD_LDS_BYTES = (MAIN_FLOATS + 1344) * 4;   // 70 912 B
-__device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* mainT = lds;
-    float* scr = lds + MAIN_FLOATS;
-    float* px = scr;          // [3][64] x_c
-    float* pd = scr + 192;    // [3][64] d_c
-    float* pg = scr + 384;    // [3][64] g_c
-    float* red = scr + 576;   // [4][3][64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = tile * TM;
-    const size_t grow0 = (size_t)row0;
-    const bool save = a.flags & PF_SAVE, deform = a.flags & PF_DEFORM;
-    const size_t Mp = (size_t)a.L.Mp;
-    const float* feat = wsb(a, WS_FEAT);
-    float* CIN = wsb(a, WS_C_IN);
-
-    if (tid < 64) {
-        const size_t gp = grow0 + tid;
-        float x[3], t, d[3];
-        load_point(a.src, row0 + tid, x, t, d);
-        const float* xc = wsb(a, WS_XC) + gp * 3;
-        const float* gc = wsb(a, WS_GC) + gp * 3;
-        px[tid] = xc[0]; px[64 + tid] = xc[1]; px[128 + tid] = xc[2];
-        pg[tid] = gc[0]; pg[64 + tid] = gc[1]; pg[128 + tid] = gc[2];
-        float v0 = d[0], v1 = d[1], v2 = d[2];
-        if (deform) {
-            const float* v = wsb(a, WS_V) + gp * 3;      // d_c = J d / (|J d| + 1e-10)   endosurf.py:684-685
-            v0 = v[0]; v1 = v[1]; v2 = v[2];
-        }
-        const float inv = (a.flags & PF_RAW_DIR) ? 1.f : 1.f / (sqrtf(v0 * v0 + v1 * v1 + v2 * v2) + 1e-10f);
-        pd[tid] = v0 * inv; pd[64 + tid] = v1 * inv; pd[128 + tid] = v2 * inv;
-    }
-    __syncthreads();
-    // small part [enc10(x_c) 63 | g_c 3 | enc4(d_c) 27 | 0 0 0] into rows 0..95 of the activation tile
-    encode3<10>(mainT, 0, px, tid);
-    if (tid < 192) mainT[swz(63 + (tid >> 6), tid & 63)] = pg[tid];
-    encode3<4>(mainT, 66, pd, tid);
-    zero_rows(mainT, 93, 96, tid);
-    __syncthreads();
-    {
-        const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 96; k += 4) CIN[(grow0 + r) * 128 + k] = mainT[swz(k, r)];
-    }
-    float* CH = wsb(a, WS_C_H);
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_C * LAYERS + l];
-        float* Hl = CH + (size_t)l * Mp * 256;
-        unsigned long long bits = 0;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            const float b = bias[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = fmaxf(v[i] + b, 0.f);
-                bits |= (unsigned long long)(v[i] > 0.f) << (4 * qi + i);
-            }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Hl, grow0, 256, row, col, v);
-        });
-        if (save)      // the ReLU masks of the backward sweep: 2 words per thread instead of 64 activations
-            reinterpret_cast<unsigned long long*>(wsb(a, WS_C_MASK))[((size_t)l * (Mp / 64) + tile) * 256 + tid] = bits;
-    };
-    {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        gemm_seg<12, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0S], 0, 2 * wave, lane);
-        __syncthreads();
-        load_tile_256(mainT, feat, grow0, 256, tid);
-        __syncthreads();
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0F], 0, 2 * wave, lane);
-        __syncthreads();
-        epi(acc, 0);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
-        acc_zero(acc);
-        if (l != 4) {
-            const int seg = l < 4 ? CF1 + (l - 1) : CF5 + (l - 5);
-            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
-        } else {   // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2, staged through the tile one part at a time
-            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4H], 0, 2 * wave, lane);
-            __syncthreads();
-            load_tile<96>(mainT, CIN, grow0, 128, tid);
-            __syncthreads();
-            gemm_seg<12, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4S], 0, 2 * wave, lane);
-            __syncthreads();
-            load_tile_256(mainT, feat, grow0, 256, tid);
-            __syncthreads();
-            gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4F], 0, 2 * wave, lane);
-        }
-        __syncthreads();
-        epi(acc, l);
-        __syncthreads();
-    }
-    smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_C * LAYERS + 8], 256, red, tid);
-    __syncthreads();
-    if (tid < 192) {
-        const int i = tid >> 6, row = tid & 63;
-        const float y = smalln_reduce<3>(red, i, row) + a.weff[a.tb.boff[NET_C * LAYERS + 8] + i];
-        wsb(a, WS_RGB)[(grow0 + row) * 3 + i] = 1.f / (1.f + expf(-y));
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
 // One launch = two segments of tiles, possibly of different networks: blocks [0, n0) run body B0 on tiles t0.., the rest run
 // body B1 on tiles t1...  Used for the short colour-less tail of a training batch (errorondepth / surface-neighbour points):
 // launched with its own network's main tiles it adds a nearly empty third round of the 512 workgroup slots to the SDF
@@ -544,7 +60,8 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 // -------------------------------------------------------------------------------------------------------------
 // infer_x3r.hip / query_x3.hip
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
-int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
+int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st, int m_rows = 0);
+int deform_jvp_x3r_with_tail(const FwdArgs& fa, const void* packed_r, int m_main, hipStream_t st);
 int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, bool save, hipStream_t st);
 int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, bool save, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
@@ -573,6 +90,17 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         // the fp32 kernels' buffers (row-major stacks; the ReLU mask words and the SDF stacks' order are this family's: PF_X3_CHAIN
         // tells the backward and the weight-gradient GEMMs)
         const void* pr = packed_x3r_part(packed_x3);
+        if (deform && !(flags & PF_X3_SDF) && aux_tail(flags, a.M_color, src.M) && a.M_color % 128 == 0) {
+            // colour-less tail behind a block-aligned main part (the fused training batch): the tail goes through the fp32 family, its
+            // dependent stages hidden in this family's 4-round launch (infer_x3r.hip k_deform_jvp_x3r_tail):
+            //   deform(tail, fp32) | [sdf + vjp](tail, fp32) + jvp(main) | sdf(main, fp32) | colour(main) | vjp(main)
+            const int Mc = a.M_color;
+            { ScopedTimer tm(KID_DEFORM_FWD, Mp - Mc, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
+            if (int e = deform_jvp_x3r_with_tail(a, pr, Mc, st)) return e;
+            { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+            if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mc, true, st)) return e;
+            return deform_vjp_x3r(src, pr, weff, ws, a.L, true, st, Mc);
+        }
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, true, st)) return e; }
         if (flags & PF_X3_SDF) { if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, true, st)) return e; }
         else { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }

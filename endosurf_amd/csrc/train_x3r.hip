@@ -16,6 +16,7 @@
 #include "tabs.h"
 #include "timing.h"
 #include "workspace.h"
+#include "point_bwd_bodies.h"
 
 namespace es {
 
@@ -130,16 +131,16 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
 
 // ---- reverse sweep of the value and J d rows --------------------------------------------------------------------------------------
 // lanes 0-15 of a lane half: the value row's adjoint of a point, lanes 16-31: the J d row's; both are gated by the value row's ReLU mask
-__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
-                                                                const float* __restrict__ xcbar, const float* __restrict__ vbar, int M_color,
-                                                                const u32x4* __restrict__ masks, float* __restrict__ A, float* __restrict__ A8, int Mp) {
+__device__ __forceinline__ void deform_bwd_x3r_body(const Tabs& tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                    const float* __restrict__ xcbar, const float* __restrict__ vbar, int M_color,
+                                                    const u32x4* __restrict__ masks, float* __restrict__ A, float* __restrict__ A8, int Mp, const int blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     float* w8L = reinterpret_cast<float*>(ldsr + XR_RING * XR_CHUNK_BYTES) + 128 * XR_ENC_LD;      // [3][256] (same carve as the tangent sweep)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const bool tan = n >= 16;
-    const int point = blockIdx.x * 64 + wave * 16 + (n & 15);      // < Mp (the grid is Mp / 64)
+    const int point = blk * 64 + wave * 16 + (n & 15);             // < Mp
     const size_t arow = (size_t)point * 2 + (tan ? 1 : 0);
     const size_t rows2 = (size_t)Mp * 2;
     float a8[3];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
     const size_t astride = rows2 * 256;
     int lsave = 7;
     const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, 2 * (n & 15) + (tan ? 1 : 0), hi, lane};
-    float* Awave = A + ((size_t)blockIdx.x * 64 + wave * 16) * 2 * 256;       // the wave's 32 consecutive rows
+    float* Awave = A + ((size_t)blk * 64 + wave * 16) * 2 * 256;              // the wave's 32 consecutive rows
     const auto asink = [&](int s, const float (&v)[8]) { rt.put(s, v, Awave + lsave * astride, 256); };
     f32x16 P[8], C[8];
     // abar_7 = mask_7 . (W8^T abar_8)  ->  adjoint of h_6 = W_7^T abar_7
@@ -202,6 +203,25 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const
         }
 }
 
+__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r(Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
+                                                                const float* __restrict__ xcbar, const float* __restrict__ vbar, int M_color,
+                                                                const u32x4* __restrict__ masks, float* __restrict__ A, float* __restrict__ A8, int Mp) {
+    deform_bwd_x3r_body(tb, chunks, weff, xcbar, vbar, M_color, masks, A, A8, Mp, (int)blockIdx.x);
+}
+// the backward counterpart of k_deform_jvp_x3r_tail (infer_x3r.hip): the colour-less tail's tangent sweep + SDF backward as fp32 tile bodies
+// (blocks [0, n0): tiles t0 ..) at the head of the main batch's deformation reverse sweep; the tail's own deformation reverse sweep
+// follows as a small fp32 launch
+__global__ __launch_bounds__(XR_THREADS, 1) void k_deform_bwd_x3r_tail(BwdArgs ba, int n0, int t0, const u32x4* __restrict__ chunks,
+                                                                     const u32x4* __restrict__ masks) {
+    if ((int)blockIdx.x < n0) {
+        deform_tan_tile(ba, t0 + (int)blockIdx.x);
+        __syncthreads();
+        sdf_bwd_tile(ba, t0 + (int)blockIdx.x);
+        return;
+    }
+    deform_bwd_x3r_body(ba.tb, chunks, ba.weff, ba.ws + ba.L.off[WS_XCBAR], ba.ws + ba.L.off[WS_VBAR_C], ba.M_color, masks, ba.ws + ba.L.off[WS_D_A],
+                        ba.ws + ba.L.off[WS_D_A8], ba.L.Mp, (int)blockIdx.x - n0);
+}
 
 // ---- colour network, reverse sweep -------------------------------------------------------------------------------------------------
 // ColorNetwork backward (point_bwd.hip color_bwd_tile): ybar_8 = rgbbar . rgb (1 - rgb), ybar_7 = M_7 (U_8^T ybar_8),
@@ -601,6 +621,7 @@ static int train_attrs() {
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_deform_tan_x3r, XT_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_bwd_x3r, XT_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_deform_bwd_x3r_tail, XT_LDS_BYTES > LEAN_LDS_BYTES ? XT_LDS_BYTES : LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_tan_x3r, XSB_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_rev_x3r<true>, XSB_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_sdf_rev_x3r<false>, XSB_LDS_BYTES)) return e;
@@ -610,14 +631,23 @@ static int train_attrs() {
     }
     return ST_OK;
 }
-// tangent sweep of all Mp points (J gbar_o -> WS_JU, tau_0 .. tau_8 -> WS_D_T0 / WS_D_T)
-int deform_tan_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, const float* d_go, hipStream_t st) {
+// tangent sweep of the points [0, m_rows) (a multiple of 128; 0: all Mp) (J gbar_o -> WS_JU, tau_0 .. tau_8 -> WS_D_T0 / WS_D_T)
+int deform_tan_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, const float* d_go, hipStream_t st, int m_rows) {
     if (int e = train_attrs()) return e;
     const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_DEFORM_TAN_X3, src.M, st);
-    hipLaunchKernelGGL(k_deform_tan_x3r, dim3((L.Mp + 127) / 128), dim3(XR_THREADS), XT_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
+    ScopedTimer tm(KID_DEFORM_TAN_X3, m_rows > 0 ? m_rows : src.M, st);
+    hipLaunchKernelGGL(k_deform_tan_x3r, dim3(((m_rows > 0 ? m_rows : L.Mp) + 127) / 128), dim3(XR_THREADS), XT_LDS_BYTES, st, src, tb, reinterpret_cast<const u32x4*>(packed_r), weff,
                        d_go, reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]), ws + L.off[WS_D_T0], ws + L.off[WS_D_T], ws + L.off[WS_JU], L.Mp);
     return hip_last("deform_tan_x3r");
+}
+// the main batch [0, m_main) through this family's reverse sweep with the tail's fp32 tangent + SDF-backward bodies at the head of the launch
+int deform_bwd_x3r_with_tail(const BwdArgs& ba, const void* packed_r, int m_main, hipStream_t st) {
+    if (int e = train_attrs()) return e;
+    ScopedTimer tm(KID_DEFORM_BWD_X3, ba.src.M, st);
+    const int n0 = (ba.L.Mp - m_main) / TM;
+    hipLaunchKernelGGL(k_deform_bwd_x3r_tail, dim3(n0 + m_main / 64), dim3(XR_THREADS), XT_LDS_BYTES > LEAN_LDS_BYTES ? XT_LDS_BYTES : LEAN_LDS_BYTES, st, ba, n0,
+                       m_main / TM, reinterpret_cast<const u32x4*>(packed_r), reinterpret_cast<const u32x4*>(ba.ws + ba.L.off[WS_D_MASK]));
+    return hip_last("deform_bwd_x3r_with_tail");
 }
 // reverse sweep of all Mp points; vbar is read for the points [0, m_color)
 int deform_bwd_x3r(const void* packed_r, const float* weff, float* ws, const WsLayout& L, int M, int m_color, hipStream_t st) {
