@@ -10,6 +10,9 @@
 // problems that accumulate into the same output): bit-identical gradients from run to run, at ~80 MB of extra traffic per launch.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "arch.h"
 #include "chain_common.h"
 #include "launch.h"
@@ -48,6 +51,7 @@ struct WgArgs {
     WgProb p[WG_MAX_PROBS];
     WgSmall s[WG_MAX_SMALL];
     int nprob, total_tasks, MC, nsmall;
+    int KW;                  // input features per task: WG_KW (fp32 kernel: [256 x 128] tiles) or 256 (split-precision kernel: the whole dW)
     float* det;              // deterministic mode: scratch of WG_DET_FLOATS floats (nullptr: fp32 atomics)
 };
 // scratch layout: [task][256][128] partial tiles | [task][256] partial bias sums | [small][task][5][256] (4 outputs + bias row)
@@ -241,14 +245,15 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
 // Slice `slot` of `nslots` of a small problem: thread = (input feature k, row-block parity); 16-row blocks, the loads of two
 // steps (2 x 16 rows of X per thread) in flight, the <= 4 adjoint columns go through LDS (double buffered, one barrier per step).
 constexpr int WS_ROWS = 16;
-template <bool DET>
+// NH: 256-thread halves of the workgroup (2: the fp32 kernel's 512 threads, 1: the split-precision kernel's 256); every half streams its own row blocks
+template <bool DET, int NH = 2>
 __device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int nslots, float* lds, float* det_slot) {
     float(*sd)[WS_ROWS][4] = reinterpret_cast<float(*)[WS_ROWS][4]>(lds);       // [half * 2 + buffer]
-    const int tid = threadIdx.x, k = tid & 255, half = tid >> 8;
+    const int tid = threadIdx.x, k = tid & 255, half = NH == 2 ? tid >> 8 : 0;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     const int nblk = (P.M + WS_ROWS - 1) / WS_ROWS;
-    const int step = 2 * nslots;
+    const int step = NH * nslots;
     // X rows up to the next multiple of 64 exist (finite padding rows of the workspace; their adjoints are read as 0)
     typedef float v4f __attribute__((ext_vector_type(4)));
     auto loadx = [&](float(&x)[WS_ROWS], int b0) {
@@ -288,7 +293,7 @@ __device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int
                 if (((m0 + r) % P.bias_stride) == 0) bsum += sdb[r][k];
     };
     float xa[WS_ROWS], xb[WS_ROWS];
-    int b0 = 2 * slot, it = 0;
+    int b0 = NH * slot, it = 0;
     if (b0 < nblk) loadx(xa, b0);
 #pragma unroll 1
     while (b0 < nblk) {
@@ -303,19 +308,24 @@ __device__ __forceinline__ void wgrad_small_task(const WgSmall& P, int slot, int
     // the two row-block parities are summed through LDS: one atomic per (output, k) and task
     __syncthreads();
     float* red = lds;
-    if (half) {
+    if (NH == 2 && half) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) red[n * 256 + k] = acc[n];
         red[1024 + k] = bsum;
     }
-    __syncthreads();
+    if (NH == 2) __syncthreads();
     if (!half) {
+        if constexpr (NH == 2) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] += red[n * 256 + k];
+            bsum += red[1024 + k];
+        }
         if constexpr (DET) {        // det_slot: [5][256] = 4 output rows + bias row of this (small problem, task)
-            for (int n = 0; n < 4; ++n) det_slot[n * 256 + k] = acc[n] + red[n * 256 + k];
-            det_slot[4 * 256 + k] = bsum + red[1024 + k];
+            for (int n = 0; n < 4; ++n) det_slot[n * 256 + k] = acc[n];
+            det_slot[4 * 256 + k] = bsum;
         } else {
-            for (int n = 0; n < P.N; ++n) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[n] + red[n * 256 + k]);
-            if (P.bias_out && k < P.N) atomicAdd(P.bias_out + k, bsum + red[1024 + k]);
+            for (int n = 0; n < P.N; ++n) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[n]);
+            if (P.bias_out && k < P.N) atomicAdd(P.bias_out + k, bsum);
         }
     }
     __syncthreads();
@@ -364,205 +374,255 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// OPT-IN split-precision variant (flag PF_X3; csrc/query_x3.hip explains the arithmetic): the same task decomposition, but both
-// operand panels are split EXACTLY into three bf16 planes on their way into LDS and the contraction runs on
-// v_mfma_f32_32x32x16_bf16 (six partial products per tile, fp32 accumulation): ~2.7x the fp32 matrix rate, which turns these GEMMs
-// from MFMA-bound into HBM-bound (each operand element is still read once per task).  A stage = 16 rows = one MFMA k-step.
+// OPT-IN split-precision variant (flag PF_X3; csrc/query_x3.hip explains the arithmetic).  Both operand panels are split EXACTLY into
+// three bf16 planes on their way into LDS and the contraction runs on v_mfma_f32_32x32x16_bf16 (six partial products per tile, fp32
+// accumulation): ~2.7x the fp32 matrix rate, which turns these GEMMs from MFMA-bound into HBM-bound -- so a task here is the WHOLE
+// [256 x 256] dW of a layer over a chunk of rows: every dA / X element is read from HBM exactly once per launch (with [256 x 128]
+// tiles the dA rows were fetched by two tasks: 4.67 GB fetched for 3.4 GB of operands, at 4.3 TB/s).
+// One workgroup = FOUR waves, one per SIMD, each with the SIMD's whole register file (256 accumulators = a [128 x 128] tile of dW, 4 x 4
+// MFMA tiles): with one wave per SIMD nothing overlaps by itself, so the stage (16 rows = one MFMA k-step) is software-pipelined by hand:
+//   * panels are written TWO stages ahead (stage s splits and writes the rows of stage s + 2 into buffer (s + 2) % 3, last read in
+//     stage s - 1's prefetches), so the fragments of stage s + 1 are already visible during stage s and are fetched between its MFMAs;
+//   * the X fragments are processed two 32-column tiles at a time (B0 / B1: the other pair is fetched meanwhile); the dA fragments (4
+//     tiles x 3 planes) are replaced plane by plane as they die, which fixes the order of the six partial products per half (always
+//     smallest class first: 2^-16, 2^-16, 2^-16, 2^-8, 2^-8, 1);
+//   * two register sets of 32 staged floats per thread (the loads of stage s + 4 are issued when stage s has split the rows of s + 2);
+//   * one MFMA per "slot" (96 per stage), the side work (ds_read / split / ds_write / global loads) distributed over the slots and
+//     pinned with sched_barrier; the stage body is branch-free (rows past the chunk's end are staged as zeros through selects).
+// Problems with few input features (first layers, skip columns: K = 39 / 52 / 93) take the same path (their missing columns are
+// whatever the clamped loads return; those output columns are never stored).
+// Measured (tools/wgrad_x3_probe.py: one [1.65 M x 256] x [1.65 M x 256] problem = the deformation launch's rows; tools/pmc_probe.sh;
+// -DES_WX_NO_MFMA / -DES_WX_NO_SPLIT builds): gaussian operands 1.31 ms at 1.56 GHz (MFMA busy 0.61); MFMAs + fragment reads alone
+// 0.78 ms at 1.80 GHz (busy 0.895); loads + split + panel writes alone 0.60 ms at 1.99 GHz (5.7 TB/s); all-zero operands 0.92 / 0.62 /
+// 0.53 ms -- the clock follows the power drawn, and the parts ADD: a stage costs 3 465 cycles of MFMA stream + ~1 585 for its 257 VALU and
+// 44 memory instructions, interleaved or not.  Two waves per SIMD (8 waves of [64 x 128], stage phases of SIMD partners in lock step or
+// offset by half a stage) measured the same 0.95-1.0 ms per deformation launch of the training step; what moved it was the operand
+// traffic ([256 x 128] tiles: 1.03 ms).
 // LDS per plane: units of 16 B = 8 consecutive ROWS of one column, [row group (2)][column] -> the A / B fragments (lane = column,
-// 8 rows) are single conflict-free ds_read_b128.  Every thread stages one (row group, column) unit of dA (512 units per stage)
-// and threads 0..255 one unit of X: 8 dword loads (row-major operands, coalesced over columns) or 2 float4 loads (fragment-ordered).
+// 8 rows) are single conflict-free ds_read_b128.  A thread stages column tid of both row groups of both operands: 16 dword loads per
+// operand (row-major, coalesced over columns) or 4 float4 loads (fragment-ordered).
 typedef unsigned wx_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WX_THREADS = 256;
 constexpr int WX_R = 16;
-constexpr int WX_A_PLANE = 2 * 256 * 16;                     // 8 KiB
-constexpr int WX_B_PLANE = 2 * WG_KW * 16;                   // 4 KiB
-constexpr int WX_BUF = 3 * (WX_A_PLANE + WX_B_PLANE);        // 36 KiB per stage buffer
-constexpr int WX_LDS_BYTES = 4 * WX_BUF;                     // ring of four: 144 KiB, one workgroup (8 waves, <= 256 registers) per CU
-static_assert(WX_LDS_BYTES >= WG_LDS_FLOATS * 4, "the small-layer slices and the bias reduction reuse the buffer as float scratch");
+constexpr int WX_KW = 256;                                   // input features per task: all of them
+constexpr int WX_PLANE = 2 * 256 * 16;                       // 8 KiB
+constexpr int WX_BUF = 6 * WX_PLANE;                         // 48 KiB per stage buffer: 3 planes of dA, 3 of X
+constexpr int WX_NBUF = 3;
+constexpr int WX_LDS_BYTES = WX_NBUF * WX_BUF;               // 144 KiB, one workgroup per CU
+static_assert(WX_LDS_BYTES >= WG_LDS_FLOATS * 4, "the small-layer slices reuse the buffer as float scratch");
 
 __device__ __forceinline__ unsigned wx_cvt_pk(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
-// 8 fp32 values -> three bf16x8 planes with v = h + m + l exactly
-__device__ __forceinline__ void wx_split8(const float (&v)[8], wx_u32x4& h, wx_u32x4& m, wx_u32x4& l) {
+template <int... Is, class F>
+__device__ __forceinline__ void wx_static_for(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>()), ...);
+}
+
+template <bool AF, bool XF, bool DET>
+__device__ __forceinline__ void wgrad_task_x3(const WgProb& P, int m0, int m1, unsigned char* lds, float* det_tile, float* det_bias) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wk = w >> 1;
+    const int lo = lane & 31, hi = lane >> 5;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+
+    f32x16 acc[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][tp][r] = 0.f;
+    const int c = tid;                                       // staging column of this thread (both row groups, both operands)
+    const int bstride = P.bias_stride;
+    float bsum = 0.f;                                        // bias gradient = column sum of dA over the rows r with r % bias_stride == 0
+    const unsigned wr_off = (unsigned)c * 16;
+    const unsigned ra_off = (unsigned)(hi * 256 + wn * 128 + lo) * 16;
+    const unsigned rb_off = 3 * WX_PLANE + (unsigned)(hi * 256 + wk * 128 + lo) * 16;
+    const int nst = (m1 - m0) / WX_R;
+    // operand addressing: 32-bit element offsets from the (uniform) base pointers; dA is a [rows][256] stack (launch_group checks)
+    const float* __restrict__ gA = P.dA;
+    const float* __restrict__ gX = P.X;
+    constexpr unsigned lda = 256;
+    const unsigned ldx = (unsigned)P.ldx;
+    const unsigned cx = min((unsigned)c, ldx - 1);           // X stacks narrower than 256 columns: clamped (those outputs are not stored)
+    const unsigned foff = (unsigned)((((c >> 6) * 16 + ((c >> 5) & 1) * 4) * 64 + (c & 31)) * 4);
+    // fragment-ordered stacks (chain_common.h frag_off): rows 8 g .. 8 g + 7 of the stage = quad 2 j + g of the tile, lane halves 0 / 1
+    auto frag_off = [&](unsigned m) { return (m >> 6) * (64u * 256u) + (8u * ((m >> 5) & 1u) + 2u * ((m >> 4) & 1u)) * 256u + foff; };
+    auto stage_row = [&](int st) { return (unsigned)(m0 + WX_R * min(st, nst - 1)); };
+
+    // one of the 16 loads of a stage (row-major: row r; fragment-ordered: the float4 of rows r .. r + 3 when r % 4 == 0)
+    auto loadA = [&](float (&v)[16], int st, int r) {
+        const unsigned m = stage_row(st);
+        if constexpr (AF) {
+            if (r % 4 == 0) {
+                const float* pa = gA + frag_off(m) + (r >> 3) * 256 + ((r >> 2) & 1) * 128;
+                const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[r + i] = t0[i];
+            }
+        } else {
+            v[r] = __builtin_nontemporal_load(gA + (m * lda + c) + r * lda);
+        }
+    };
+    auto loadB = [&](float (&v)[16], int st, int r) {
+        const unsigned m = stage_row(st);
+        if constexpr (XF) {
+            if (r % 4 == 0) {
+                const float* px = gX + frag_off(m) + (r >> 3) * 256 + ((r >> 2) & 1) * 128;
+                const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(px));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[r + i] = t0[i];
+            }
+        } else {
+            v[r] = __builtin_nontemporal_load(gX + (m * ldx + cx) + r * ldx);
+        }
+    };
+    // two floats -> word j of the three planes (v = h + m + l exactly)
+    auto split2 = [&](float x0, float x1, bool live, wx_u32x4& h, wx_u32x4& m, wx_u32x4& l, int j) {
+        x0 = live ? x0 : 0.f; x1 = live ? x1 : 0.f;
         const unsigned hh = wx_cvt_pk(x0, x1);
         float r0 = x0 - __uint_as_float(hh << 16), r1 = x1 - __uint_as_float(hh & 0xffff0000u);
         const unsigned mm = wx_cvt_pk(r0, r1);
         r0 -= __uint_as_float(mm << 16); r1 -= __uint_as_float(mm & 0xffff0000u);
         h[j] = hh; m[j] = mm; l[j] = wx_cvt_pk(r0, r1);
-    }
-}
-
-struct WxRegs { float a[8]; float b[8]; };
-
-template <bool AF, bool XF, bool DET>
-__device__ __forceinline__ void wgrad_task_x3(const WgProb& P, int kb, int m0, int m1, unsigned char* lds, float* det_tile, float* det_bias) {
-    constexpr int KW = WG_KW;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = w & 3, kh = w >> 2;
-    const int lo = lane & 31, hi = lane >> 5;
-    const int kcol0 = kb * KW;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-
-    f32x16 acc[2][2];
-    acc_zero(acc);
-    // staging roles: A unit (ga, na) for every thread, B unit (gb, kk) for threads 0..255
-    const int ga = tid >> 8, na = tid & 255;
-    const bool has_b = tid < 256;
-    const int gb = (tid >> 7) & 1, kk = tid & 127;
-    const int colB = kcol0 + kk;
-    const bool okB = has_b && (XF || colB < P.ldx);
-    // bias gradient = column sums of dA over the rows r with r % bias_stride == 0 (strides 1, 2 or 4; row groups start at
-    // multiples of 8), taken from the staging registers
-    const bool do_bias = P.bias_out != nullptr && kb == 0;
-    float bsum = 0.f;
-    // fragment-ordered operands: the 8 rows of row group g of a stage are the quads (q = 2j + g, hi = 0 / 1) of the tile
-    auto frag_base = [&](const float* base, int m) {
-        return base + (size_t)(m >> 6) * (64 * 256) + (size_t)((8 * ((m >> 5) & 1) + 2 * ((m >> 4) & 1)) * 256);
     };
-    const size_t foffA = (size_t)((((na >> 6) * 16 + ((na >> 5) & 1) * 4 + ga) * 64 + (na & 31)) * 4);
-    const int cB = (XF ? colB : 0);
-    const size_t foffB = (size_t)((((cB >> 6) * 16 + ((cB >> 5) & 1) * 4 + gb) * 64 + (cB & 31)) * 4);
-
-    auto gload = [&](WxRegs& R, int m) {
-        if constexpr (AF) {
-            const float* pa = frag_base(P.dA, m) + foffA;
-            const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa));
-            const v4f t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa + 32 * 4));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { R.a[i] = t0[i]; R.a[4 + i] = t1[i]; }
-        } else {
-            const float* pa = P.dA + (size_t)(m + 8 * ga) * P.lda + na;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) R.a[r] = __builtin_nontemporal_load(pa + (size_t)r * P.lda);
-        }
-        if (okB) {
-            if constexpr (XF) {
-                const float* px = frag_base(P.X, m) + foffB;
-                const v4f t0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(px));
-                const v4f t1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(px + 32 * 4));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { R.b[i] = t0[i]; R.b[4 + i] = t1[i]; }
-            } else {
-                const float* px = P.X + (size_t)(m + 8 * gb) * P.ldx + colB;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) R.b[r] = __builtin_nontemporal_load(px + (size_t)r * P.ldx);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) R.b[r] = 0.f;
-        }
+    auto bias_add = [&](const float (&v)[16], bool live) {
+        const float s4 = (v[0] + v[4]) + (v[8] + v[12]);
+        const float s2 = s4 + ((v[2] + v[6]) + (v[10] + v[14]));
+        const float s1 = s2 + (((v[1] + v[3]) + (v[5] + v[7])) + ((v[9] + v[11]) + (v[13] + v[15])));
+        const float sel = bstride == 1 ? s1 : (bstride == 2 ? s2 : s4);
+        bsum += live ? sel : 0.f;
     };
-    auto sstore = [&](const WxRegs& R, int buf, bool live = true) {      // live = false: a clamped repeat of the last stage (no bias sums)
-        unsigned char* Ab = lds + buf * WX_BUF;
-        unsigned char* Bb = Ab + 3 * WX_A_PLANE;
+    auto wr3 = [&](int buf, int operand, int g, const wx_u32x4& h, const wx_u32x4& m, const wx_u32x4& l) {
+        unsigned char* p = lds + buf * WX_BUF + operand * 3 * WX_PLANE + g * 4096 + wr_off;
+        *reinterpret_cast<wx_u32x4*>(p) = h;
+        *reinterpret_cast<wx_u32x4*>(p + WX_PLANE) = m;
+        *reinterpret_cast<wx_u32x4*>(p + 2 * WX_PLANE) = l;
+    };
+    wx_u32x4 A[4][3], B0[2][3], B1[2][3];
+    auto rdA = [&](int buf, int t, int p) { A[t][p] = *reinterpret_cast<const wx_u32x4*>(lds + buf * WX_BUF + ra_off + p * WX_PLANE + t * 512); };
+    auto rdB0 = [&](int buf, int j, int p) { B0[j][p] = *reinterpret_cast<const wx_u32x4*>(lds + buf * WX_BUF + rb_off + p * WX_PLANE + j * 512); };
+    auto rdB1 = [&](int buf, int j, int p) { B1[j][p] = *reinterpret_cast<const wx_u32x4*>(lds + buf * WX_BUF + rb_off + p * WX_PLANE + (2 + j) * 512); };
+    auto bar = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    float pa0[16], pb0[16], pa1[16], pb1[16];        // register sets 0 / 1
+    // One stage: MFMAs on the fragments of buffer CUR; fetches the rest of CUR's and the first fragments of NXT; splits the set
+    // (rows of stage s + 2; `live` = they exist) into buffer WRT and reloads it with the rows of stage `reload`.
+    auto stage = [&](auto cur_c, auto nxt_c, auto wrt_c, float (&sa)[16], float (&sb)[16], bool live, int reload) {
+        constexpr int CUR = decltype(cur_c)::value, NXT = decltype(nxt_c)::value, WRT = decltype(wrt_c)::value;
+        constexpr int TA0[6] = {1, 2, 0, 1, 0, 0}, TB0[6] = {1, 0, 2, 0, 1, 0};      // first half:  (a1 b1) (a2 b0) (a0 b2) | (a1 b0) (a0 b1) | (a0 b0)
+        constexpr int TA1[6] = {0, 1, 2, 0, 1, 0}, TB1[6] = {2, 1, 0, 1, 0, 0};      // second half: (a0 b2) (a1 b1) (a2 b0) | (a0 b1) (a1 b0) | (a0 b0)
         wx_u32x4 h, m, l;
-        wx_split8(R.a, h, m, l);
-        const int oa = (ga * 256 + na) * 16;
-        *reinterpret_cast<wx_u32x4*>(Ab + oa) = h;
-        *reinterpret_cast<wx_u32x4*>(Ab + WX_A_PLANE + oa) = m;
-        *reinterpret_cast<wx_u32x4*>(Ab + 2 * WX_A_PLANE + oa) = l;
-        if (do_bias && live) {
-            if (P.bias_stride == 1) bsum += ((R.a[0] + R.a[1]) + (R.a[2] + R.a[3])) + ((R.a[4] + R.a[5]) + (R.a[6] + R.a[7]));
-            else if (P.bias_stride == 2) bsum += (R.a[0] + R.a[2]) + (R.a[4] + R.a[6]);
-            else bsum += R.a[0] + R.a[4];
-        }
-        if (has_b) {
-            wx_split8(R.b, h, m, l);
-            const int ob = (gb * KW + kk) * 16;
-            *reinterpret_cast<wx_u32x4*>(Bb + ob) = h;
-            *reinterpret_cast<wx_u32x4*>(Bb + WX_B_PLANE + ob) = m;
-            *reinterpret_cast<wx_u32x4*>(Bb + 2 * WX_B_PLANE + ob) = l;
-        }
-    };
-    auto compute = [&](int buf) {
-        const unsigned char* Ab = lds + buf * WX_BUF + (hi * 256 + nb * 64 + lo) * 16;
-        const unsigned char* Bb = lds + buf * WX_BUF + 3 * WX_A_PLANE + (hi * KW + kh * 64 + lo) * 16;
-        wx_u32x4 a[2][3], b[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[t][p] = *reinterpret_cast<const wx_u32x4*>(Ab + p * WX_A_PLANE + t * 32 * 16);
-                b[t][p] = *reinterpret_cast<const wx_u32x4*>(Bb + p * WX_B_PLANE + t * 32 * 16);
+        // dA plane 0 died with the last MFMA of the previous stage (needed from slot 16 on)
+        rdA(CUR, 0, 0); rdA(CUR, 1, 0); rdA(CUR, 2, 0); rdA(CUR, 3, 0);
+        wx_static_for(std::make_integer_sequence<int, 96>(), [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int half = i / 48, q = (i % 48) / 8, t = (i % 8) / 2, j = i % 2;
+#ifndef ES_WX_NO_MFMA
+            if constexpr (half == 0)
+                acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wx_bf16x8, A[t][TA0[q]]), __builtin_bit_cast(wx_bf16x8, B0[j][TB0[q]]),
+                                                                    acc[t][j], 0, 0, 0);
+            else
+                acc[t][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wx_bf16x8, A[t][TA1[q]]), __builtin_bit_cast(wx_bf16x8, B1[j][TB1[q]]),
+                                                                        acc[t][2 + j], 0, 0, 0);
+#endif
+            // ---- side work of the slot ----
+            if constexpr (i == 7) bias_add(sa, live);
+            if constexpr (i >= 2 && i < 8) rdB1(CUR, (i - 2) & 1, 2 - (i - 2) / 2);              // X tiles 2, 3 of this stage: planes 2, 1, 0
+#ifndef ES_WX_NO_SPLIT
+            if constexpr (i >= 8 && i < 56 && (i - 8) % 3 == 0) {                                 // 16 pair splits: operand, row group, word
+                constexpr int k = (i - 8) / 3, g = (k / 4) % 2, jj = k % 4;
+                if constexpr (k < 8) split2(sa[8 * g + 2 * jj], sa[8 * g + 2 * jj + 1], live, h, m, l, jj);
+                else split2(sb[8 * g + 2 * jj], sb[8 * g + 2 * jj + 1], true, h, m, l, jj);     // dead rows: dA is zero, X is finite (clamped loads)
             }
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};       // smallest partial products first
-        // partial product q of all four accumulators before q + 1 (dependent MFMAs on one accumulator 3 issues apart): measured 5 %
-        // faster here than six dependent MFMAs per accumulator in a row (the opposite holds in query_x3.hip's loop)
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-                    acc[t][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wx_bf16x8, a[t][TA[q]]),
-                                                                        __builtin_bit_cast(wx_bf16x8, b[tp][TB[q]]), acc[t][tp], 0, 0, 0);
+            if constexpr (i == 18) wr3(WRT, 0, 0, h, m, l);
+            if constexpr (i == 30) wr3(WRT, 0, 1, h, m, l);
+#ifndef ES_WX_NO_LOAD
+            if constexpr (i >= 32 && i < 48) loadA(sa, reload, i - 32);
+#endif
+            if constexpr (i == 42) wr3(WRT, 1, 0, h, m, l);
+            if constexpr (i == 54) wr3(WRT, 1, 1, h, m, l);
+#endif
+#ifndef ES_WX_NO_LOAD
+            if constexpr (i >= 56 && i < 72) loadB(sb, reload, i - 56);
+#endif
+            if constexpr (i >= 60 && i < 66) rdB0(NXT, (i - 60) & 1, (i - 60) / 2);               // next stage, X tiles 0, 1
+            if constexpr (i >= 72 && i < 76) rdA(NXT, i - 72, 2);                                 // dA plane 2 died with slot 71
+            if constexpr (i >= 88 && i < 92) rdA(NXT, i - 88, 1);                                 // dA plane 1 died with slot 87
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        bar();
     };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 
-    // Software pipeline: the kernel is HBM-latency bound (one workgroup per CU), so the loads of stage st + 3 are issued at the
-    // start of stage st (four register sets, ~2.5 stages = 60 KB per CU in flight; with two sets the launch sustained 3.4 TB/s =
-    // 24 KB per stage time, Little's law) and the stages rotate through four LDS buffers with ONE barrier per stage.
-    const int nst = (m1 - m0) / WX_R;           // multiple of 4 (chunks are multiples of 64 rows): the body handles 4 stages
-    WxRegs p0, p1, p2, p3;
-    gload(p0, m0);
-    gload(p1, m0 + WX_R);
-    gload(p2, m0 + 2 * WX_R);
-    sstore(p0, 0);
-    __syncthreads();
-#pragma unroll 1
-    // Loads are issued UNCONDITIONALLY (clamped to the last stage): behind `if (st + 4 < nst)` the compiler cannot count the outstanding
-    // loads and waits for all of them (s_waitcnt vmcnt(0)) before each stage store; [sdf] 1.13 -> 0.95 ms, [deform] 1.06 -> 1.00 ms.
-    for (int st = 0; st < nst; st += 4) {
-        gload(p3, m0 + WX_R * (st + 3));
-        compute(0);
-        sstore(p1, 1);
-        __syncthreads();
-        gload(p0, m0 + WX_R * min(st + 4, nst - 1));
-        compute(1);
-        sstore(p2, 2);
-        __syncthreads();
-        gload(p1, m0 + WX_R * min(st + 5, nst - 1));
-        compute(2);
-        sstore(p3, 3);
-        __syncthreads();
-        gload(p2, m0 + WX_R * min(st + 6, nst - 1));
-        compute(3);
-        sstore(p0, 0, st + 4 < nst);
-        __syncthreads();
+    // prologue: rows of stages 0 / 1 into buffers 0 / 1, sets reloaded with stages 2 / 3, first fragments of buffer 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { loadA(pa0, 0, r); loadB(pb0, 0, r); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { loadA(pa1, 1, r); loadB(pb1, 1, r); }
+    {
+        wx_u32x4 h, m, l;
+        auto stage_set = [&](int buf, int operand, const float (&v)[16], bool live) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) split2(v[8 * g + 2 * jj], v[8 * g + 2 * jj + 1], live, h, m, l, jj);
+                wr3(buf, operand, g, h, m, l);
+            }
+        };
+        stage_set(0, 0, pa0, true); bias_add(pa0, true);
+        stage_set(0, 1, pb0, true);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { loadA(pa0, 2, r); loadB(pb0, 2, r); }
+        stage_set(1, 0, pa1, 1 < nst); bias_add(pa1, 1 < nst);
+        stage_set(1, 1, pb1, true);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { loadA(pa1, 3, r); loadB(pb1, 3, r); }
     }
-    // acc[t][tp][r]: n = nb*64 + 32 t + (r & 3) + 8 (r >> 2) + 4 hi ;  k = kb*128 + kh*64 + 32 tp + lo
+    bar();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t) { rdA(0, t, 1); rdA(0, t, 2); }
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-            const int k = kcol0 + kh * 64 + 32 * tp + lo;
+    for (int p = 0; p < 3; ++p) { rdB0(0, 0, p); rdB0(0, 1, p); }
+#pragma unroll 1
+    for (int st = 0; st < nst; st += 6) {       // stages past the end of the chunk multiply zero panels
+        stage(I0(), I1(), I2(), pa0, pb0, st + 2 < nst, st + 4);
+        stage(I1(), I2(), I0(), pa1, pb1, st + 3 < nst, st + 5);
+        stage(I2(), I0(), I1(), pa0, pb0, st + 4 < nst, st + 6);
+        stage(I0(), I1(), I2(), pa1, pb1, st + 5 < nst, st + 7);
+        stage(I1(), I2(), I0(), pa0, pb0, st + 6 < nst, st + 8);
+        stage(I2(), I0(), I1(), pa1, pb1, st + 7 < nst, st + 9);
+    }
+    // acc[t][tp][r]: n = wn*128 + 32 t + (r & 3) + 8 (r >> 2) + 4 hi ;  k = wk*128 + 32 tp + lo
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int k = wk * 128 + 32 * tp + lo;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = nb * 64 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if constexpr (DET) det_tile[n * WG_KW + (k - kcol0)] = acc[t][tp][r];
+                const int n = wn * 128 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if constexpr (DET) det_tile[n * WX_KW + k] = acc[t][tp][r];
                 else if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
-    if (do_bias) {      // the two row groups of a column are summed through LDS (all stages consumed)
-        float* red = reinterpret_cast<float*>(lds);
-        red[ga * 256 + na] = bsum;
-        __syncthreads();
-        if (tid < 256) {
-            const float sum = red[tid] + red[256 + tid];
-            if constexpr (DET) det_bias[tid] = sum;
-            else if (tid < P.N) atomicAdd(P.bias_out + tid, sum);
-        }
+    if (P.bias_out != nullptr) {
+        if constexpr (DET) det_bias[tid] = bsum;
+        else if (tid < P.N) atomicAdd(P.bias_out + tid, bsum);
     }
+    __syncthreads();        // the next user of the LDS buffer (small-layer slices) must not overtake this task's last fragment reads
 }
 
 template <int NET, bool DET>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_x3(WgArgs a) {
+__global__ __launch_bounds__(WX_THREADS, 1) void k_wgrad_x3(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wxlds[];
     float* wlds = reinterpret_cast<float*>(wxlds);
     const int task = blockIdx.x;
@@ -570,7 +630,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_x3(WgArgs a) {
     const bool small_first = task < a.total_tasks / 2;
     if (small_first) {
 #pragma unroll 1
-        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET, 1>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
         __syncthreads();
     }
     int pi = 0;
@@ -578,28 +638,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_x3(WgArgs a) {
     for (int i = 1; i < a.nprob; ++i)
         if (task >= a.p[i].task_begin) pi = i;
     const WgProb& P = a.p[pi];
-    const int local = task - P.task_begin;
-    const int kblk = (P.K + WG_KW - 1) / WG_KW;
-    int kb, mc;
-    wg_decode(local, kblk, (P.M + a.MC - 1) / a.MC, kb, mc);
+    const int mc = task - P.task_begin;           // one task per row chunk: the whole [256 x 256] dW
     const int m0 = mc * a.MC, m1 = min(m0 + a.MC, P.M);
-    float* dt = DET ? a.det + (size_t)task * WG_DET_TILE : nullptr;
+    float* dt = DET ? a.det + (size_t)task * (256 * WX_KW) : nullptr;
     float* db = DET ? a.det + WG_DET_BIAS_OFF + (size_t)task * 256 : nullptr;
-    if constexpr (NET == 1) {
+    if constexpr (NET == 1) {      // only the SDF network's stacks can be fragment-ordered
         if (P.a_frag) {
-            if (P.x_frag) wgrad_task_x3<true, true, DET>(P, kb, m0, m1, wxlds, dt, db);
-            else wgrad_task_x3<true, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+            if (P.x_frag) wgrad_task_x3<true, true, DET>(P, m0, m1, wxlds, dt, db);
+            else wgrad_task_x3<true, false, DET>(P, m0, m1, wxlds, dt, db);
         } else {
-            if (P.x_frag) wgrad_task_x3<false, true, DET>(P, kb, m0, m1, wxlds, dt, db);
-            else wgrad_task_x3<false, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+            if (P.x_frag) wgrad_task_x3<false, true, DET>(P, m0, m1, wxlds, dt, db);
+            else wgrad_task_x3<false, false, DET>(P, m0, m1, wxlds, dt, db);
         }
     } else {
-        wgrad_task_x3<false, false, DET>(P, kb, m0, m1, wxlds, dt, db);
+        wgrad_task_x3<false, false, DET>(P, m0, m1, wxlds, dt, db);
     }
     if (!small_first) {
-        __syncthreads();
 #pragma unroll 1
-        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
+        for (int i = 0; i < a.nsmall; ++i) wgrad_small_task<DET, 1>(a.s[i], task, a.total_tasks, wlds, small_slot(i));
     }
 }
 
@@ -611,12 +667,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgArgs a, int round) {
     if (pi < a.nprob) {
         const WgProb& P = a.p[pi];
         if (P.round != round) return;
-        const int kblk = (P.K + WG_KW - 1) / WG_KW, nchunk = (P.M + a.MC - 1) / a.MC;
+        const int kblk = (P.K + a.KW - 1) / a.KW, nchunk = (P.M + a.MC - 1) / a.MC;
+        const size_t tile = (size_t)256 * a.KW;
         for (int e = tid0; e < P.N * P.K; e += stride) {
-            const int n = e / P.K, k = e % P.K, kb = k / WG_KW, kk = k % WG_KW;
+            const int n = e / P.K, k = e % P.K, kb = k / a.KW, kk = k % a.KW;
             float s = 0.f;
             for (int mc = 0; mc < nchunk; ++mc)
-                s += a.det[(size_t)(P.task_begin + wg_encode(kb, mc, kblk, nchunk)) * WG_DET_TILE + n * WG_KW + kk];
+                s += a.det[(size_t)(P.task_begin + wg_encode(kb, mc, kblk, nchunk)) * tile + n * a.KW + kk];
             P.out[(size_t)n * P.ldo + k] += s;
         }
         if (P.bias_out)
@@ -646,7 +703,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgArgs a, int round) {
     }
 }
 
-static int wg_kblk(const WgProb& p) { return (p.K + WG_KW - 1) / WG_KW; }
+static int wg_kblk(const WgProb& p, int kw) { return (p.K + kw - 1) / kw; }
 
 static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, int kid_timer, long long rows, float* det, bool x3, hipStream_t st) {
     const int kid = kid_timer == KID_WGRAD_D_X3 ? KID_WGRAD_D : (kid_timer == KID_WGRAD_S_X3 ? KID_WGRAD_S : (kid_timer == KID_WGRAD_C_X3 ? KID_WGRAD_C : kid_timer));
@@ -671,9 +728,10 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
     // rows per task: the smallest chunk (multiple of 64 rows) for which the whole group fits in ONE full round of the 512
     // workgroup slots (2 per CU x 256 CUs): long tasks amortise the prologue and the fp32-atomic epilogue (one round
     // measured 1-4.5 % faster than three), and a second, nearly empty round would double the launch
+    const int KW = x3 ? WX_KW : WG_KW;
     auto count = [&](int mc) {
         long long t = 0;
-        for (int i = 0; i < nprob; ++i) t += (long long)wg_kblk(probs[i]) * ((probs[i].M + mc - 1) / mc);
+        for (int i = 0; i < nprob; ++i) t += (long long)wg_kblk(probs[i], KW) * ((probs[i].M + mc - 1) / mc);
         return t;
     };
     ES_REQUIRE(nsmall <= WG_MAX_SMALL, "too many small weight-gradient problems in one group");
@@ -691,14 +749,14 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
         ES_REQUIRE(!probs[i].x_frag || (probs[i].ldx == 256 && probs[i].K == 256), "fragment-ordered inputs are [64 x 256] tiles");
         ES_REQUIRE(kid == KID_WGRAD_S || !(probs[i].x_frag || probs[i].a_frag), "fragment-ordered operands: SDF launch only");
         probs[i].task_begin = total;
-        total += wg_kblk(probs[i]) * ((probs[i].M + MC - 1) / MC);
+        total += wg_kblk(probs[i], KW) * ((probs[i].M + MC - 1) / MC);
         probs[i].round = 0;
         for (int j = 0; j < i; ++j)
             if (probs[j].out == probs[i].out && probs[j].round >= probs[i].round) probs[i].round = probs[j].round + 1;
         max_round = probs[i].round > max_round ? probs[i].round : max_round;
         a.p[i] = probs[i];
     }
-    a.nprob = nprob; a.total_tasks = total; a.MC = MC; a.nsmall = nsmall;
+    a.nprob = nprob; a.total_tasks = total; a.MC = MC; a.nsmall = nsmall; a.KW = KW;
     for (int i = 0; i < nsmall; ++i) {
         ES_REQUIRE(small[i].K == 256 && small[i].N <= 4, "small weight-gradient problems are [<=4 x 256]");
         small[i].round = 0;
@@ -715,13 +773,13 @@ static int launch_group(WgProb* probs, int nprob, WgSmall* small, int nsmall, in
                 hipLaunchKernelGGL(k_wgrad_reduce, dim3(32, nprob + nsmall), dim3(256), 0, st, a, r);
         };
         if (det) {
-            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
-            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL((k_wgrad_x3<2, true>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, true>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
+            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, true>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((k_wgrad_x3<2, true>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
         } else {
-            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
-            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL((k_wgrad_x3<2, false>), grid, dim3(WG_THREADS), WX_LDS_BYTES, st, a);
+            if (kid == KID_WGRAD_D) hipLaunchKernelGGL((k_wgrad_x3<0, false>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
+            else if (kid == KID_WGRAD_S) hipLaunchKernelGGL((k_wgrad_x3<1, false>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((k_wgrad_x3<2, false>), grid, dim3(WX_THREADS), WX_LDS_BYTES, st, a);
         }
         reduce();
         return ST_OK;
