@@ -20,31 +20,37 @@ constexpr int Q16_LDS_BYTES = (Q16_MAIN + Q16_AUX + 1024) * 4;
 // element (k, row) of a 16-row k-major tile; the XOR keeps ds_write_b128 epilogue stores and the A-fragment reads conflict-free
 __device__ __forceinline__ int swz16(int k, int r) { return k * T16 + (r ^ (((k >> 1) & 3) << 2)); }
 
-// acc[ni] += A[16 rows][0 .. 16*KG) * B[..][16 cols of n-tile nt0+ni], ni < 4 (this wave's 64 columns)
+// acc[ni] += A[16 rows][0 .. 16*KG) * B[..][16 cols of n-tile nt0+ni], ni < 4 (this wave's 64 columns).
+// A 1 024-point launch is one workgroup per CU = ONE wave per SIMD: nothing hides a weight load but distance.  The weights of a k-group
+// (4 float4 per lane) are requested THREE groups (48 MFMAs, ~1 500 cycles) before their use through a ring of four register sets, and
+// the first three groups of the NEXT layer before this layer's epilogue and barriers (``Wnext``; the caller passes ``primed`` to the
+// next call).  With one group of distance every group waited ~100-400 cycles for L2 (57 stall cycles per 32-cycle MFMA).
+struct Ring16 { float4 b[4][4]; };
 template <int KG>
-__device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const float4* __restrict__ W, int nt0, int lane) {
-    const int lo = lane & 15, hi = lane >> 4;
-    const float4* wl = W + lane;
-    float4 b0[4], b1[4];
-    auto loadB = [&](float4(&b)[4], int g) {
+__device__ __forceinline__ void ring16_load(Ring16& R, const float4* __restrict__ W, int nt0, int lane, int g) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) b[ni] = wl[(size_t)((nt0 + ni) * KG + g) * 64];
-    };
-    auto comp = [&](const float4(&b)[4], int g) {
+    for (int ni = 0; ni < 4; ++ni) R.b[g & 3][ni] = W[(size_t)((nt0 + ni) * KG + g) * 64 + lane];
+}
+template <int KG>
+__device__ __forceinline__ void ring16_prime(Ring16& R, const float4* __restrict__ W, int nt0, int lane) {
+#pragma unroll
+    for (int g = 0; g < 3 && g < KG; ++g) ring16_load<KG>(R, W, nt0, lane, g);
+}
+template <int KG, int KGN = 16>
+__device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const float4* __restrict__ W, int nt0, int lane, Ring16& R, bool primed = false,
+                                       const float4* __restrict__ Wnext = nullptr) {
+    const int lo = lane & 15, hi = lane >> 4;
+    if (!primed) ring16_prime<KG>(R, W, nt0, lane);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (g + 3 < KG) ring16_load<KG>(R, W, nt0, lane, g + 3);
+        else if (Wnext != nullptr) ring16_load<KGN>(R, Wnext, nt0, lane, g + 3 - KG);      // the ring slot (g + 3) & 3 is free: KG % 4 == 0 here
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = At[swz16(16 * g + 4 * j + hi, lo)];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(b[ni], j), acc[ni], 0, 0, 0);
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(R.b[g & 3][ni], j), acc[ni], 0, 0, 0);
         }
-    };
-    loadB(b0, 0);
-#pragma unroll 1
-    for (int g = 0; g < KG; g += 2) {
-        if (g + 1 < KG) loadB(b1, g + 1);
-        comp(b0, g);
-        if (g + 2 < KG) loadB(b0, g + 2);
-        if (g + 1 < KG) comp(b1, g + 1);
     }
 }
 
@@ -100,7 +106,7 @@ __device__ __forceinline__ void encode3_16(float* At, int kbase, const float* px
 }
 
 template <bool DEFORM>
-__global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs tb, const float4* __restrict__ packed,
+__global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs tb, const float4* __restrict__ packed,
                                                              const float* __restrict__ weff, float* __restrict__ sdf_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * T16;
     const int nt0 = 4 * wave;
+    Ring16 ring;
 
     if (tid < 16) {
         float x[3], t, d[3];
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
             zero4(acc);
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + 0]);
-            gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane);
+            gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane, ring, false, packed + tb.p16off[1]);
             relu_epi(acc, bq);
         }
         __syncthreads();
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
             zero4(acc);
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + l]);
-            gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane);
+            gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane, ring, true, l < 7 ? packed + tb.p16off[l + 1] : nullptr);
             __syncthreads();
             epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
                 if (l == 3 && col >= 204) {                                  // IDR skip: [h(204) | enc(52)]
@@ -203,7 +210,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
         zero4(acc);
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + 0]);
-        gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane);
+        gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane, ring);
+        ring16_prime<16>(ring, packed + tb.p16off[9], nt0, lane);
         sp_epi(acc, bq);
     }
     __syncthreads();
@@ -214,8 +222,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_query_sdf16(PointSrc src, Tabs 
         const int pi = l <= 4 ? 8 + l : 8 + l + 1;          // P16_SEGS order: SF0..SF3, SF4M, SF4A, SF5..SF7
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + l]);
-        gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane);
-        if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane);
+        // the skip layer's extra columns use the ring in between: no priming across it
+        const bool chain_next = l != 4 && l < 7;
+        const int pn = l + 1 <= 4 ? 8 + l + 1 : 8 + l + 2;
+        gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane, ring, l != 5, chain_next ? packed + tb.p16off[pn] : nullptr);
+        if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane, ring);
         __syncthreads();
         sp_epi(acc, bq);
         __syncthreads();
