@@ -28,8 +28,12 @@ __device__ __forceinline__ int swz16(int k, int r) { return k * T16 + (r ^ (((k 
 struct Ring16 { float4 b[4][4]; };
 template <int KG>
 __device__ __forceinline__ void ring16_load(Ring16& R, const float4* __restrict__ W, int nt0, int lane, int g) {
+    const int slot = g & 3;
+#ifdef ES_Q16_NO_W          // dev probe: every k-group of every layer reads the same (L1-resident) weights
+    g = 0;
+#endif
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) R.b[g & 3][ni] = W[(size_t)((nt0 + ni) * KG + g) * 64 + lane];
+    for (int ni = 0; ni < 4; ++ni) R.b[slot][ni] = W[(size_t)((nt0 + ni) * KG + g) * 64 + lane];
 }
 template <int KG>
 __device__ __forceinline__ void ring16_prime(Ring16& R, const float4* __restrict__ W, int nt0, int lane) {
