@@ -120,3 +120,17 @@ def test_documented_limits_of_the_split():
     scale = dA.double().abs().t() @ X.double().abs()
     ex3 = float(((_gemm(X, dA, 1).double() - ref).abs() / scale).max())
     assert ex3 < 2.0 ** -7, ex3                                           # at least the high plane's 8 bits survive
+
+
+@pytest.mark.parametrize("rows", [64, 128, 320, 1088, 6464 + 64])
+def test_split_gemm_row_counts_that_do_not_fill_the_pipeline(rows):
+    """The split-precision kernel processes a row chunk in groups of six 16-row stages (two register sets x three LDS buffers) and stages
+    the rows past the end of a chunk as zeros: chunks of 4, 8, 20, 68 stages and a problem cut into several tasks must all give the plain sum."""
+    rng = np.random.default_rng(rows)
+    X = torch.from_numpy(rng.normal(size=(rows, 256)).astype(np.float32)).cuda()
+    dA = torch.from_numpy(rng.normal(size=(rows, 256)).astype(np.float32)).cuda()
+    ref = dA.double().t() @ X.double()
+    scale = dA.double().abs().t() @ X.double().abs()
+    for split in (1, 0):
+        err = float(((_gemm(X, dA, split).double() - ref).abs() / scale).max())
+        assert err < 1e-6, (rows, split, err)
