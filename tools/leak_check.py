@@ -6,7 +6,10 @@ import bench as B
 from endosurf_amd import EndoSurfRenderer
 from endosurf_amd.trainer import SyntheticScene, Trainer
 dev = torch.device("cuda", 0)
-r = EndoSurfRenderer(dict(B.RENDER_CFG), B.NET_CFG, device=dev)
+cfg = dict(B.CONFIGS[2])
+r = EndoSurfRenderer(B.render_cfg(cfg), dict(B.NET_CFG, use_deform=cfg["use_deform"]), device=dev)
+if os.environ.get("ES_SPLIT_BF16") == "1":
+    r.engine.split_precision = True
 tr = Trainer(r)
 sc = SyntheticScene(dev, seed=1)
 b = sc.batch(1024)
