@@ -34,8 +34,11 @@ class Engine:
         self.n_weff = int(self.lib.es_weff_floats())
         self.n_packed = int(self.lib.es_packed_floats())
         import os
+        # Supported environment variables (README): ES_SPLIT_BF16, ES_DETERMINISTIC (here), ES_WORKSPACE_GB (renderer).  Everything else
+        # below is an attribute only -- measurement code sets ``renderer.engine.<name>``, nothing reads development switches from the
+        # environment any more.
         # ray marching evaluates its proposals in blocks of this many steps with early exit (0: one launch over all proposals)
-        self.march_block = int(os.environ.get("ES_MARCH_BLOCK", "32"))
+        self.march_block = 32
         # deterministic mode: batch sums and weight gradients are reduced in a fixed order instead of with fp32 atomics
         # (bit-identical results from run to run; a few % slower).  Also settable per renderer: ``renderer.engine.deterministic = True``
         self.deterministic = os.environ.get("ES_DETERMINISTIC", "0") not in ("0", "", "false", "False")
@@ -46,11 +49,11 @@ class Engine:
         # NOT the default; also settable per renderer through render_cfg["split_precision"] / ``renderer.engine.split_precision = True``
         self.split_precision = os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "", "false", "False")
         self._x3 = None
-        self.x3_query_min = int(os.environ.get("ES_X3_QUERY_MIN", "8193"))
+        self.x3_query_min = 8193
         self.x3_infer_min = 16384      # points: below this a launch of 64/128-point tiles does not fill the chip
         # split-precision mode: grad-enabled evaluations run the split-precision TRAINING chain (infer_x3r.hip with saves +
         # train_x3r.hip); False keeps the fp32 chain kernels under the split-precision queries / weight gradients (round-2 behaviour)
-        self.x3_train_chain = os.environ.get("ES_X3_TRAIN", "1") not in ("0", "", "false", "False")
+        self.x3_train_chain = True
         # ... including the SDF network's training kernels (experimental: parity-tested, but slower than the fp32 SDF kernels)
         self.x3_sdf_chain = os.environ.get("ES_X3_SDF", "0") not in ("0", "", "false", "False")
 

@@ -471,11 +471,11 @@ class _RenderFn(torch.autograd.Function):
                 outs["go"].append(pctx.view("go")[:n_ * S].view(n_, S, 3).clone())
             cat = {k: torch.cat(v, 0) for k, v in outs.items()}
             ctx.eik_den = (eik_acc[1] + 1e-6).reshape(1)
-            eng.last_eik_den = ctx.eik_den
             eik = eik_acc[0] / ctx.eik_den[0]
-            ctx.mark_non_differentiable(cat["wmax_idx"])
+            den_out = ctx.eik_den.clone()
+            ctx.mark_non_differentiable(cat["wmax_idx"], den_out)
             return (cat["color"], cat["depth"], cat["go"], eik, cat["weights"], cat["weight_max"], cat["cdf"], cat["wmax_idx"],
-                    eng.zeros(0, 1), eng.zeros(0, 3))
+                    eng.zeros(0, 1), eng.zeros(0, 3), den_out)
         ctx.chunk_rays = 0
         mid = eng.mid_z(z, sample_dist)
         fused = aux_x is not None and aux_x.shape[0] > 0 and P_ % 64 == 0
@@ -484,19 +484,19 @@ class _RenderFn(torch.autograd.Function):
         sdf_all, go_all = pctx.view("sdf"), pctx.view("go")
         a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
         out = eng.composite_forward(a)
-        eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)
-        eng.last_eik_den = eik_den          # the eikonal term's normaliser of the last render (exact data-parallel mode reads it)
+        eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)      # the eikonal term's normaliser (exact data-parallel mode reads it from the outputs)
         eik = out["eik_acc"][0] / eik_den[0]
         ctx.pctx, ctx.eik_den = pctx, eik_den
         ctx.n_aux = aux_x.shape[0] if fused else 0
         gradients_o = go_all[:P_].view(N, S, 3).clone()           # own storage: the 8 GB workspace must not outlive backward
         aux_sdf = sdf_all[P_:].clone() if fused else eng.zeros(0, 1)
         aux_go = go_all[P_:].clone() if fused else eng.zeros(0, 3)
-        ctx.mark_non_differentiable(out["wmax_idx"])
-        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf, aux_go
+        den_out = eik_den.clone()
+        ctx.mark_non_differentiable(out["wmax_idx"], den_out)
+        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf, aux_go, den_out
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go):
+    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go, _g_den=None):
         eng = ctx.eng
         if not (ctx.flags & _lib.PF_SAVE):
             raise RuntimeError("render was run without saved activations; cannot backpropagate")
@@ -739,7 +739,7 @@ class EndoSurfRenderer(nn.Module):
         ret = self.render_core(rays[:, :3], rays[:, 3:6], rays[:, 8], z, sample_dist,
                                cos_anneal_ratio=self._cos_anneal(iter_step), eval=eval, _rays=rays, _aux=aux_points)
         n_samples = z.shape[1]
-        extra = {"aux_sdf": ret["aux_sdf"], "aux_gradients_o": ret["aux_gradients_o"]} if aux_points is not None else {}
+        extra = {"aux_sdf": ret["aux_sdf"], "aux_gradients_o": ret["aux_gradients_o"], "eik_den": ret["eik_den"]} if aux_points is not None else {}
         return {
             **extra,
             "color_map": ret["color_map"],
@@ -766,14 +766,14 @@ class EndoSurfRenderer(nn.Module):
             aux_x = _aux[0].detach().to(torch.float32).contiguous()
             aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
         flags = self._flags(weff)
-        color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go = _RenderFn.apply(
+        color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go, eik_den = _RenderFn.apply(
             weff, packed, var, self.engine, _rays, z, float(sample_dist), cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), flags, aux_x, aux_t,
             self._chunk_rays(z.shape[0], z.shape[1], flags))
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
         s_val = _SValFn.apply(var, self.engine)                 # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
         return {"color_map": color, "depth_map": depth, "gradients_o": g_o, "gradient_o_error": eik, "cdf": cdf,
-                "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go}
+                "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go, "eik_den": eik_den}
 
     # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
     def _point_eval(self, x, t, dirs=None, canonical=False):

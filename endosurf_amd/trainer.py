@@ -32,7 +32,7 @@ def compute_loss(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weigh
 
 
 def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int, weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1,
-                       u_perturb=None, u_neigh=None, loss_kernel: bool = True, exact: bool = False):
+                       u_perturb=None, u_neigh=None, loss_kernel: bool = True, exact: bool = False, group=None):
     """Same loss as compute_loss, but the auxiliary points of errorondepth (N) and surface_neighbour_error (2N) are evaluated
     inside the render's kernel launches (endosurf_amd extension ``aux_points``) instead of two extra tiny point evaluations."""
     rays = renderer._rays32(batch["rays"])
@@ -71,13 +71,13 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
             # depends on them through 1 / D_k per term -- and every term is scaled by the world size: the mean over the ranks of the
             # per-rank gradients is then exactly the gradient of the concatenated batch.
             import torch.distributed as dist
-            world = dist.get_world_size() if dist.is_initialized() else 1
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
             den = renderer.engine.empty(5)
             _LossFn.sums(renderer.engine, rays, eod_pts, mask_gt, cmask, valid_sn, den)
-            den_local_eik = renderer.engine.last_eik_den            # sum relax + 1e-6 of this rank's render
+            den_local_eik = ret["eik_den"]            # sum relax + 1e-6 of THIS render (returned by it, not read from engine state)
             den[4:5].copy_(den_local_eik - 1e-6)
             if world > 1:
-                dist.all_reduce(den)
+                dist.all_reduce(den, group=group)
             eik = eik * (float(world) * den_local_eik[0] / (den[4] + 1e-6))
             exact_args = (den, float(world))
         total, t = _LossFn.apply(ret["color_map"], ret["depth_map"], eik, a_sdf, a_go, renderer.engine, rays, eod_pts,
@@ -97,7 +97,6 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
 class _LossFn(torch.autograd.Function):
     """All six loss terms + total and their gradients in one HIP launch (es_train_loss)."""
 
-    @staticmethod
     @staticmethod
     def sums(eng, rays, eod_pts, mask, cmask, valid_sn, out):
         """This rank's normalisers {sum cmask, sum inside, sum valid x mask, n_valid} -> out[0:4] (first launch of the exact mode)."""
@@ -348,8 +347,9 @@ class Trainer:
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
                  loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
-                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False, exact_denominators: bool = False):
+                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False, exact_denominators: bool = False, group=None):
         self.renderer = renderer
+        self.group = group                                  # torch.distributed process group of the data-parallel ranks (None: the default group)
         self.force_collective = bool(force_collective)      # issue the gradient all-reduce even at world size 1 (RCCL smoke test)
         groups = renderer.get_train_params()
         self.params = [p for k in groups for p in groups[k]]
@@ -375,7 +375,7 @@ class Trainer:
             if schedule != "fused":
                 raise ValueError("exact_denominators needs the fused schedule")
             import functools
-            self.loss_fn = functools.partial(compute_loss_fused, exact=True)
+            self.loss_fn = functools.partial(compute_loss_fused, exact=True, group=group)
 
     def update_learning_rate(self, global_step: int):
         lr = self.lr_init * lr_factor(global_step, self.n_iter, self.warm_up_end, self.lr_alpha)
@@ -413,22 +413,30 @@ class Trainer:
         with torch.cuda.device(self.renderer.device):
             return self._train_step_graph(batch, global_step)
 
+    def _graph_key(self, batch, global_step: int):
+        """Everything the captured launch sequence depends on besides device memory: the batch shape and the HOST-evaluated branches of a
+        step (importance sampling on / off at this iteration, ray-marching block mode, kernel family switches, deterministic reductions).
+        A change re-captures instead of silently replaying the old branch."""
+        r, e = self.renderer, self.renderer.engine
+        upsample = global_step >= r.important_begin_iter and r.n_importance > 0
+        return (tuple(batch["rays"].shape), tuple(sorted(batch)), bool(upsample), int(e.march_block), bool(e.split_precision), bool(e.x3_train_chain),
+                int(e.x3_query_min), bool(e.deterministic), bool(self.data_parallel))
+
     def _train_step_graph(self, batch, global_step: int):
         r, opt = self.renderer, self.optimizer
         if not isinstance(opt, FlatAdam) or self.loss_fn is not compute_loss_fused:
             raise ValueError("train_step_graph needs the fused schedule and FlatAdam (the defaults; exact_denominators puts a collective "
                              "into the forward pass and is not captured)")
         g = getattr(self, "_graph", None)
-        shape = tuple(batch["rays"].shape)
-        if g is None or g["shape"] != shape:
+        key = self._graph_key(batch, global_step)
+        if g is None or g["key"] != key:
             scal = r.engine.zeros(4)          # step_size, bc2_sqrt, grad_scale | cos_anneal: written by es_train_schedule inside the step
-            g = self._graph = dict(shape=shape, batch={k: torch.empty_like(v) for k, v in batch.items()}, scal=scal,
+            g = self._graph = dict(key=key, batch={k: torch.empty_like(v) for k, v in batch.items()}, scal=scal,
                                    state=torch.zeros(2, device=r.device, dtype=torch.float64), next=None, eager=0, graph=None, loss=None)
-            opt.scalars_dev, r._cos_anneal_dev = scal, scal[3:]
         world = 1
         if self.data_parallel:
             import torch.distributed as dist
-            world = dist.get_world_size() if dist.is_initialized() else 1
+            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         for k, v in batch.items():
             g["batch"][k].copy_(v, non_blocking=True)
         t = opt.step_count + 1
@@ -436,6 +444,9 @@ class Trainer:
             g["state"].copy_(torch.tensor([global_step - 1, t - 1], dtype=torch.float64))
         g["next"] = (global_step + 1, t + 1)
         pg = opt.param_groups[0]
+        # the host's copy of the schedule follows the device's (same formula, both in double precision): checkpoints written from a
+        # graph-mode run carry the learning rate of the step they were written at, like the reference's (trainer_endosurf.py:85-92)
+        self.update_learning_rate(global_step)
 
         def schedule():
             from . import _lib
@@ -458,26 +469,32 @@ class Trainer:
         def finish(flat):
             if self.data_parallel:
                 from .parallel import allreduce_flat
-                allreduce_flat(flat, force=self.force_collective)
+                allreduce_flat(flat, group=self.group, force=self.force_collective)
                 opt.step(grad=flat, variance_in_grad=True)
 
-        if g["graph"] is None and g["eager"] < 2:        # lazy initialisation outside a capture: two ordinary steps
-            g["eager"] += 1
-            loss, flat = body()
-            finish(flat)
-            return loss
-        if g["graph"] is None:
-            count = opt.step_count
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g["loss"], g["flat"] = body()
-            opt.step_count = count                         # capturing launches nothing: the step count advances with the replays
-            g["graph"] = graph
-        g["graph"].replay()
-        if self.data_parallel:
-            finish(g["flat"])                              # (opt.step advances the count itself)
-        else:
-            opt.step_count = t
+        # The device-resident scalars are visible to the launches of THIS call only: an eager train_step / render / checkpoint afterwards
+        # must see the host schedule again (pg["lr"], grad_scale, get_cos_anneal_ratio(iter_step)), not the last graph step's values.
+        opt.scalars_dev, r._cos_anneal_dev = g["scal"], g["scal"][3:]
+        try:
+            if g["graph"] is None and g["eager"] < 2:        # lazy initialisation outside a capture: two ordinary steps
+                g["eager"] += 1
+                loss, flat = body()
+                finish(flat)
+                return loss
+            if g["graph"] is None:
+                count = opt.step_count
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    g["loss"], g["flat"] = body()
+                opt.step_count = count                         # capturing launches nothing: the step count advances with the replays
+                g["graph"] = graph
+            g["graph"].replay()
+            if self.data_parallel:
+                finish(g["flat"])                              # (opt.step advances the count itself)
+            else:
+                opt.step_count = t
+        finally:
+            opt.scalars_dev, r._cos_anneal_dev = None, None
         r.model._epoch += 1                                # parameters changed behind Python's back: packed weights are stale
         r.model._pack_cache = None
         return g["loss"]
@@ -490,13 +507,13 @@ class Trainer:
             if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update
                 from .parallel import allreduce_flat
                 g = self.optimizer.flat_grad(include_variance=True)
-                world = allreduce_flat(g, force=self.force_collective)
+                world = allreduce_flat(g, group=self.group, force=self.force_collective)
                 self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
             else:
                 self.optimizer.step()
             return loss.detach(), terms, ret
         if self.data_parallel:
             from .parallel import allreduce_gradients
-            allreduce_gradients(self.params)
+            allreduce_gradients(self.params, group=self.group)
         self.optimizer.step()
         return loss.detach(), terms, ret

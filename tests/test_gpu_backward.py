@@ -87,14 +87,20 @@ def _render_scalar(ret, c, dt, dev):
             + ret["s_val"].sum() * 0.01)
 
 
+FLOOR = 5e-3
+WIDER = {}          # (case, tensor) -> budget: tensors whose render-level gradient error exceeds FLOOR without the reference's own
+                    # fp32-vs-fp64 error (from 32 sampled entries) explaining it
+
+
 def _check_rows(rows, c, prefix64, prefix32, name, r=None):
     """Per parameter tensor, against the fp64 reference / oracle:
       (1) norm within 3x the reference's own fp32-vs-fp64 norm difference (golden norm summaries);
       (2) DIRECTION: relative L2 error of the whole tensor vs autograd on the fp64 oracle <= max(3x the reference's own
-          fp32-vs-fp64 relative error, 2e-2) -- the reference's own error is estimated from the 32 sampled entries per tensor the
-          goldens hold for both of its precisions (grad64/*/val vs grad/*/val);
+          fp32-vs-fp64 relative error, FLOOR = 5e-3; round 4: was 2e-2) -- the reference's own error is estimated from the 32 sampled
+          entries per tensor the goldens hold for both of its precisions (grad64/*/val vs grad/*/val); tensors that need more than
+          the floor are listed by name in WIDER with the measured reason;
       (3) the same 32 sampled entries of the HIP gradient against the reference's fp64 values, same budget."""
-    bad = {}
+    bad, table = {}, {}
     named = dict(r.named_parameters()) if r is not None else {}
     for k, (rel, nref, ngot) in rows.items():
         if nref < 1e-9:
@@ -111,7 +117,8 @@ def _check_rows(rows, c, prefix64, prefix32, name, r=None):
         samp_norm = np.linalg.norm(v64)
         # the reference's own relative error, from the sampled entries (scaled to the tensor: the samples' share of the norm varies)
         ref_rel = np.linalg.norm(v32 - v64) / (samp_norm + 1e-30) if samp_norm > 1e-3 * n64 * np.sqrt(len(idx) / max(len(idx), 1)) else 0.0
-        budget = max(3 * ref_rel, 2e-2)
+        budget = max(3 * ref_rel, WIDER.get((name, k), FLOOR))
+        table[k] = (rel, budget, ref_rel)
         if rel > budget:
             bad[k] = ("direction", rel, budget, ref_rel)
             continue
@@ -122,6 +129,8 @@ def _check_rows(rows, c, prefix64, prefix32, name, r=None):
             err = np.linalg.norm(got - v64) / (np.linalg.norm(v64) + np.sqrt(len(idx)) * rms)
             if err > budget:
                 bad[k] = ("samples", err, budget, ref_rel)
+    _dump(f"budget_{prefix64}_{name}" + ("_split" if os.environ.get("ES_SPLIT_BF16", "0") not in ("0", "") else ""),
+          {k: v for k, v in table.items()})
     assert not bad, (name, bad)
 
 
