@@ -98,7 +98,7 @@ __device__ __forceinline__ void deform_jvp_x3r_body(const PointSrc& src, const T
     f32x16 P[8], C[8];
     init(C, 0);
     gemm_r<4>(C, ws, enc_val);
-    copy8(P, C);
+    copy8_acc(P, C);
     const size_t mrow = ((size_t)point) * 2 + hi;
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
@@ -115,9 +115,9 @@ __device__ __forceinline__ void deform_jvp_x3r_body(const PointSrc& src, const T
             const float h = m ? z : 0.f;
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
-        }, NoSide(), [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Ul, 256); });
+        }, NoSide(), [&](int s, const float (&v)[8]) { if (SAVE) rt.put<256>(s, v, Ul); });
         if (!tan && point < Mp) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     {   // x_c = x + W8 relu(z_7) + b8 on the value columns, v = d + W8 (mask_7 . tau_7) on the tangent columns
         u32x4 mk = {0u, 0u, 0u, 0u};
@@ -194,13 +194,13 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     const int point = blockIdx.x * 128 + wave * 32 + n;
     constexpr bool live = true;                                // Mp is a multiple of 128 (workspace.h): every point of a block is a workspace row
     float* arow = adj + (wave * 32 + n) * XR_ENC_LD;
-    float x[3], t, d[3];
-    load_point(src, point, x, t, d);
+    // (g_c and, at the end, the point itself are (re)read where they are needed instead of living in registers across the sweep)
     float g[3] = {0.f, 0.f, 0.f};
     if (live) { g[0] = ws_gc[(size_t)point * 3]; g[1] = ws_gc[(size_t)point * 3 + 1]; g[2] = ws_gc[(size_t)point * 3 + 2]; }
     for (int i = tid; i < 3 * 256; i += XR_THREADS) w8L[i] = weff[tb.woff[NET_D * LAYERS + 8] + i];
-    const size_t mrow = ((size_t)(live ? point : 0)) * 2 + hi;
-    u32x4 mk = masks[((size_t)7 * Mp) * 2 + mrow];
+    const unsigned mrow = (unsigned)(live ? point : 0) * 2u + (unsigned)hi;      // 32-bit lane index against a wave-uniform layer base
+    const size_t mstride = (size_t)Mp * 2;
+    u32x4 mk = (masks + 7 * mstride)[mrow];
     __syncthreads();
     WStream ws;
     ws.g = chunks; ws.ring = ldsr; ws.k = XR_DR_CHUNK0; ws.wave = wave; ws.lane = lane;
@@ -220,18 +220,18 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
     int lsave = 7;
     const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, n, hi, lane};
     float* Rwave = R + ((size_t)blockIdx.x * 128 + wave * 32) * 256;       // the wave's 32 rows (Mp is a multiple of 128: all of them exist)
-    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Rwave + lsave * rstride, 256); };
+    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) rt.put<256>(s, v, Rwave + lsave * rstride); };
     gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const int f = 32 * b + 8 * q + 4 * hi + i;
         const float v = fmaf(w8L[f], g[0], fmaf(w8L[256 + f], g[1], w8L[512 + f] * g[2]));
         return mask_get(mk, b, 4 * q + i) ? v : 0.f;
     }, NoSide(), rsink);
-    copy8(P, C);
+    copy8_acc(P, C);
     // layers 6 .. 1: r_l = mask_l . (adjoint of h_l),  adjoint of h_{l-1} = W_l^T r_l
 #pragma unroll 1
     for (int l = 6; l >= 1; --l) {
-        mk = masks[((size_t)l * Mp) * 2 + mrow];
+        mk = (masks + l * mstride)[mrow];
         if (l == 3) {           // the output of DR4 is the adjoint of [h_3 (204) | enc (52)]: keep the encoding part
 #pragma unroll
             for (int b = 6; b < 8; ++b)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
                 st_kstep(Rrow + 3 * rstride, 14, z8); st_kstep(Rrow + 3 * rstride, 15, z8);
             }
         } else gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, val, NoSide(), rsink);
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     // r_0 = mask_0 . (adjoint of h_0);  adjoint of the encoding += W_0^T r_0 (52 outputs: accumulator group 0 only)
     mk = masks[mrow];
@@ -273,6 +273,9 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
         }
     // the two lane halves of a point wrote disjoint features of its row; same wave, so the LDS writes are ordered before the reads
     if (hi == 0 && live) {   // g_o[j] = g_c[j] + sum_k adj[k] * d enc_k / d x_j   (position part of the encoding, observed-space x)
+        float x[3], t, d[3];
+        load_point(src, point, x, t, d);
+        g[0] = ws_gc[(size_t)point * 3]; g[1] = ws_gc[(size_t)point * 3 + 1]; g[2] = ws_gc[(size_t)point * 3 + 2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float go = g[j] + arow[j];
@@ -361,14 +364,18 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     ws.e0 = XR_SDF_FWD_CHUNKS; ws.b0 = XR_SDF_CHUNK0; ws.b1 = XR_SI_CHUNK0 + (COLOR ? 0 : 16);
     ws.start();
 
-    float* Srow = SACT + (size_t)point * 256 + 4 * hi;                            // + layer Mp 256 + 16 s (+ 8): this lane's pieces
+    // per-lane rows of the [..][Mp][256] stacks as a block-uniform base + ONE 32-bit lane offset (64-bit per-lane pointers of four
+    // streams were what this kernel spilled)
+    const size_t blk0 = (size_t)blockIdx.x * 128;
+    const unsigned loff = (unsigned)(wave * 32 + n) * 256u + 4u * (unsigned)hi;     // + layer Mp 256 + 16 s (+ 8): this lane's pieces
+    float* Sblk = SACT + blk0 * 256;
     // the side stream: the layer input whose softplus' the reverse GEMM of k-step kk needs
     const auto side = [&](int kk, int t, int) {
         if (t != 1 && t != 4) return;
         const int r = kk - (KR0 + 16);                       // SR7 reads z_7 from registers
         if (r < 0 || r >= 8 * 16) return;
         const int gi = r >> 4, s = r & 15, layer = gi <= 2 ? 6 - gi : 7 - gi, piece = t == 4;     // SR6 SR5 SR4A SR4M SR3 SR2 SR1 SR0
-        const float* srcp = Srow + (size_t)layer * lstride + 16 * s + 8 * piece;                 // s_{layer+1} = softplus(z_layer)
+        const float* srcp = (Sblk + (size_t)layer * lstride) + (loff + (unsigned)(16 * s + 8 * piece));      // s_{layer+1} = softplus(z_layer)
         unsigned char* dst = zring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
@@ -383,30 +390,30 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return softplus100_native(P[b][4 * q + i]);
     };
-    copy8(P, C);
+    copy8_acc(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
-        float* Sl = Srow + (size_t)(l - 1) * lstride;          // s_l = this GEMM's operand
+        float* Sl = (Sblk + (size_t)(l - 1) * lstride) + loff;      // s_l = this GEMM's operand
         gemm_rs<16, 2, false, 2>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { st_kstep(Sl, s, v); });
         if (l == 4) gemm_r<4>(C, ws, enc_val, side);           // NeRF skip: + encoding part (SF4A follows SF4M)
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     // P = z_7
     if (COLOR) {       // geometry features = rows 1 .. 256 of the last layer
         init8(C, biasL + 8 * 256, hi);
-        float* S8 = Srow + (size_t)7 * lstride;
+        float* S8 = (Sblk + (size_t)7 * lstride) + loff;
         gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(S8, s, v); });
-        float* fo = ws_feat + (size_t)point * 256;
+        float* fo = (ws_feat + blk0 * 256) + loff;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(fo + 32 * b + 8 * q + 4 * hi) = make_float4(C[b][4 * q], C[b][4 * q + 1], C[b][4 * q + 2], C[b][4 * q + 3]);
+                *reinterpret_cast<float4*>(fo + 32 * b + 8 * q) = make_float4(C[b][4 * q], C[b][4 * q + 1], C[b][4 * q + 2], C[b][4 * q + 3]);
     }
     {
         float s0 = 0.f;
-        float* S8 = Srow + (size_t)7 * lstride;
+        float* S8 = (Sblk + (size_t)7 * lstride) + loff;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -430,29 +437,42 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
 #pragma unroll
                 for (int r = 0; r < 16; ++r) A[b][r] = 0.f;
     };
-    float* Rrow = RHO + (size_t)point * 256 + 4 * hi;
+    float* Rblk = RHO + blk0 * 256;
     int lsave = 7;
-    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(Rrow + lsave * lstride, s, v); };
+    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep((Rblk + lsave * lstride) + loff, s, v); };
     zero(C, 8);
     gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return sigmoid100(P[b][4 * q + i]) * w8L[32 * b + 8 * q + 4 * hi + i];
     }, side, rsink);
-    copy8(P, C);
+    copy8_acc(P, C);
     int kb = 0;                                                  // first k-step of the running GEMM (its side-stream slots)
     const auto rho_val = [&](int s, int j) -> float {
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         const float sv = reinterpret_cast<const float*>(zring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
         return dphi_from_s(sv) * P[b][4 * q + i];
     };
-    f32x16 E[8];                                                 // adjoint of the encoding input (blocks 0, 1): skip part + layer 0
-    zero(E, 2);
+    // adjoint of the encoding input (accumulator blocks 0, 1): the skip layer's part is PARKED in this point's LDS row (the encoding
+    // itself is dead once the forward pass is through) until layer 0's arrives -- kept in accumulators across layers 3 .. 1 it would be
+    // a third live array next to P and C (288 of the 256 accumulation registers: the spills of round 3)
+    f32x16 E[8];
+    const auto park = [&](bool add) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
+                if (f < 39) erow[f] = add ? erow[f] + E[b][r] : E[b][r];
+            }
+    };
 #pragma unroll 1
     for (int l = 6; l >= 1; --l) {
         lsave = l;
         if (l == 4) {                                            // encoding part of the skip layer's input adjoint, same operand rho_4
             kb = ws.k;
+            zero(E, 2);
             gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);
+            park(false);
             kb = ws.k;
             zero(C, 8);
             gemm_r<16, 2, true>(C, ws, rho_val, side);
@@ -461,25 +481,22 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
             zero(C, 8);
             gemm_rs<16, 2, true, (SAVE ? 2 : 0)>(C, ws, rho_val, side, rsink);
         }
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     kb = ws.k;
     lsave = 0;
-    gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);           // += W_0^T rho_0
-    // g_c[j] = sum_k adj[k] * d enc_k / d x_j
-    __syncthreads();                                             // everybody is done with the encoding rows
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
-            if (f < 39) erow[f] = E[b][r];
-        }
+    zero(E, 2);
+    gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);           // W_0^T rho_0
+    park(true);
+    // g_c[j] = sum_k adj[k] * d enc_k / d x_j   (a point's row is written and read by its own wave only: LDS operations of a wave are ordered)
     if (SAVE) {      // (same wave: the LDS writes above are ordered before these reads; column 39 is the zero written at the start)
 #pragma unroll
         for (int k = 0; k < 20; k += 4) st4(ADJEPS + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
     }
     if (hi == 0) {
+        // (x_c is read again here instead of living in three registers across both sweeps: ws_xc holds it -- written by the
+        // deformation kernel, or by this lane at the top of the kernel)
+        x[0] = ws_xc[(size_t)point * 3]; x[1] = ws_xc[(size_t)point * 3 + 1]; x[2] = ws_xc[(size_t)point * 3 + 2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float gv = erow[j];
@@ -527,14 +544,16 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     const bool live = SAVE || point < Mcp;
     const size_t pl = live ? point : 0;
     float xc[3], gc[3], dc[3];
-    {
+    // (read again before the skip layer instead of living in nine registers across layers 1 .. 3)
+    const auto load_small = [&]() {
         float x[3], t, d[3];
         load_point(src, (int)pl, x, t, d);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xc[c] = ws_xc[pl * 3 + c]; gc[c] = ws_gc[pl * 3 + c]; dc[c] = DEFORM ? ws_v[pl * 3 + c] : d[c]; }
         const float inv = 1.f / (sqrtf(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]) + 1e-10f);
         dc[0] *= inv; dc[1] *= inv; dc[2] *= inv;
-    }
+    };
+    load_small();
     for (int i = tid; i < 8 * 256; i += XR_THREADS) biasL[i] = weff[tb.boff[NET_C * LAYERS + (i >> 8)] + (i & 255)];
     for (int i = tid; i < 3 * 256; i += XR_THREADS) w8L[i] = weff[tb.woff[NET_C * LAYERS + 8] + i];
     if (tid < 3) w8L[3 * 256 + tid] = weff[tb.boff[NET_C * LAYERS + 8] + tid];
@@ -543,14 +562,17 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
     ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane; ws.b0 = XR_C_CHUNK0;
     ws.start();
 
-    const float* frow = ws_feat + pl * 256;
+    // per-lane addresses as a block-uniform base + a 32-bit lane offset (one register instead of a 64-bit pair per stream)
+    const size_t blk0 = (size_t)blockIdx.x * 128;
+    const unsigned lrow = (unsigned)(wave * 32 + n);       // (dead lanes of the last block read their own row: the buffers have Mp >= 128 gridDim rows)
+    const float* fblk = ws_feat + blk0 * 256;
     const auto side = [&](int kk, int t, int) {                    // geometry features of k-step s of CF0F / CF4F
         if (t != 1 && t != 4) return;
         int s = kk - XC_K_0F;
         if (s < 0 || s >= 16) s = kk - XC_K_4F;
         if (s < 0 || s >= 16) return;
         const int piece = t == 4;
-        const float* srcp = frow + 16 * s + 4 * hi + 8 * piece;      // features 32 b + 16 p + 4 hi (+ 8): the k order of the operand
+        const float* srcp = fblk + (lrow * 256u + (unsigned)(16 * s + 4 * hi + 8 * piece));      // features 32 b + 16 p + 4 hi (+ 8): the k order of the operand
         unsigned char* dst = fring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
@@ -580,34 +602,35 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
         if (SAVE) mask_set(mk, b, 4 * q + i, z > 0.f);
         return fmaxf(z, 0.f);
     };
-    const size_t mrow = pl * 2 + hi;
+    const unsigned mrow = (unsigned)pl * 2u + (unsigned)hi;       // 32-bit lane index against a wave-uniform layer base
+    const size_t mstride = (size_t)Mp * 2;
     const size_t hstride = (size_t)Mp * 256;
-    float* Hrow = CH + pl * 256 + 4 * hi;                     // + (l - 1) Mp 256: h_l of this lane's point
     const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, n, hi, lane};
     const size_t wrow0 = (size_t)blockIdx.x * 128 + wave * 32;      // the wave's 32 rows (SAVE: whole blocks of workspace rows)
     init8(C, biasL, hi);
-    gemm_rs<6, 2, false, (SAVE ? 4 : 0)>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, CIN + wrow0 * 128, 128); });
+    gemm_rs<6, 2, false, (SAVE ? 4 : 0)>(C, ws, small_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put<128>(s, v, CIN + wrow0 * 128); });
     kb = ws.k;
     gemm_r<16, 2, true>(C, ws, feat_val, side);
-    copy8(P, C);
+    copy8_acc(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         init8(C, biasL + l * 256, hi);
         float* Hl = CH + (size_t)(l - 1) * hstride + wrow0 * 256;
         mk = u32x4{0u, 0u, 0u, 0u};
-        gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put(s, v, Hl, 256); });
-        if (SAVE) masks[((size_t)(l - 1) * Mp) * 2 + mrow] = mk;
+        gemm_rs<16, 2, false, (SAVE ? 4 : 0)>(C, ws, relu_val, side, [&](int s, const float (&v)[8]) { if (SAVE) rt.put<256>(s, v, Hl); });
+        if (SAVE) (masks + (l - 1) * mstride)[mrow] = mk;
         if (l == 4) {       // skip layer: input = [h(256) | small(93) | feat(256)] / sqrt2
+            load_small();
             gemm_r<6>(C, ws, small_val, side);
             kb = ws.k;
             gemm_r<16, 2, true>(C, ws, feat_val, side);
         }
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     {
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
         mk = u32x4{0u, 0u, 0u, 0u};
-        float* H8 = Hrow + (size_t)7 * hstride;
+        float* H8 = CH + (size_t)7 * hstride + blk0 * 256 + (lrow * 256u + 4u * (unsigned)hi);      // h_8 of this lane's point (SAVE: every lane is live)
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -623,7 +646,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_fwd_x3r(PointSrc src, T
                 }
                 if (SAVE) st4(H8 + 32 * b + 8 * q, h4[0], h4[1], h4[2], h4[3]);
             }
-        if (SAVE) masks[((size_t)7 * Mp) * 2 + mrow] = mk;
+        if (SAVE) (masks + 7 * mstride)[mrow] = mk;
         d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
         if (hi == 0 && live) {
             float* o = ws_rgb + (size_t)point * 3;

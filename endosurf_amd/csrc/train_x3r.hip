@@ -87,7 +87,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
     f32x16 P[8], C[8];
     zero8(C);
     gemm_r<4>(C, ws, enc_val);
-    copy8(P, C);
+    copy8_acc(P, C);
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         const bool skip = l == 4;                          // IDR skip: input of layer 4 = [tau(204) | tau_0(52)] (1/sqrt2 folded into W4)
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_tan_x3r(PointSrc src, 
             const float h = mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;      // layer 3: mask bits of features >= 204 are 0
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
-        }, NoSide(), [&](int s, const float (&v)[8]) { rt.put(s, v, Tl, 256); });
-        copy8(P, C);
+        }, NoSide(), [&](int s, const float (&v)[8]) { rt.put<256>(s, v, Tl); });
+        copy8_acc(P, C);
     }
     {   // tau_8 = mask_7 . (W_7 tau_7);  J gbar_o = gbar_o + W_8 tau_8
         const u32x4 mk = masks[((size_t)7 * Mp) * 2 + mrow];
@@ -163,7 +163,7 @@ __device__ __forceinline__ void deform_bwd_x3r_body(const Tabs& tb, const u32x4*
     int lsave = 7;
     const RowTile rt{w8L + 3 * 256 + 4 + wave * 32 * XR_TILE_LD, 2 * (n & 15) + (tan ? 1 : 0), hi, lane};
     float* Awave = A + ((size_t)blk * 64 + wave * 16) * 2 * 256;              // the wave's 32 consecutive rows
-    const auto asink = [&](int s, const float (&v)[8]) { rt.put(s, v, Awave + lsave * astride, 256); };
+    const auto asink = [&](int s, const float (&v)[8]) { rt.put<256>(s, v, Awave + lsave * astride); };
     f32x16 P[8], C[8];
     // abar_7 = mask_7 . (W8^T abar_8)  ->  adjoint of h_6 = W_7^T abar_7
     zero8(C);
@@ -173,7 +173,7 @@ __device__ __forceinline__ void deform_bwd_x3r_body(const Tabs& tb, const u32x4*
         const float v = fmaf(w8L[f], a8[0], fmaf(w8L[256 + f], a8[1], w8L[512 + f] * a8[2]));
         return mask_get(mk, b, 4 * q + i) ? v : 0.f;
     }, NoSide(), asink);
-    copy8(P, C);
+    copy8_acc(P, C);
 #pragma unroll 1
     for (int l = 6; l >= 1; --l) {
         mk = masks[((size_t)l * Mp) * 2 + mrow];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void deform_bwd_x3r_body(const Tabs& tb, const u32x4*
             const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             st_kstep(Arow + 3 * astride, 14, z8); st_kstep(Arow + 3 * astride, 15, z8);
         } else gemm_rs<16, 2, false, 4>(C, ws, val, NoSide(), asink);
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     // abar_0 = mask_0 . (W_1^T abar_1): no further GEMM (the adjoint of the encoding input has no parameter gradient)
     mk = masks[mrow];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
         const float v = fmaf(w8L[f], y8[0], fmaf(w8L[256 + f], y8[1], w8L[512 + f] * y8[2]));
         return mask_get(mk, b, 4 * q + i) ? v : 0.f;
     }, NoSide(), ysink);
-    copy8(P, C);
+    copy8_acc(P, C);
     const auto val = [&](int s, int j) -> float {                // ybar_l = mask_l . (adjoint of h_{l+1})
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return mask_get(mk, b, 4 * q + i) ? P[b][4 * q + i] : 0.f;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
             zero8(C);
             gemm_rs<16, 2, false, 2>(C, ws, val, NoSide(), ysink);
         }
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     // the two lane halves of a point wrote disjoint features of its row; same wave, so the LDS writes are ordered before the reads
     if (hi == 0) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tab
     f32x16 P[8], C[8];
     zero8(C);
     gemm_r<4>(C, ws, enc_val, side);                              // pi_0 (its k-steps 2, 3 stage the first two operand k-steps of layer 1)
-    copy8(P, C);
+    copy8_acc(P, C);
     int kb = 0;
     float z2v[8];
     float* Trow = TAU + (size_t)point * 256 + 4 * hi;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tab
         zero8(C);
         gemm_rs<16, 2, true, 4>(C, ws, tau_val, side, tsink);
         if (l == 4) gemm_r<4>(C, ws, enc_val, side);              // NeRF skip: + W_4[:, 256:] tau_0
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     {   // tau_8 = phi'(z_7) pi_7 and zeta_7: no further GEMM (the tangent of the last layer is not needed)
         const float* S8 = Srow + (size_t)7 * lstride;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_rev_x3r(Tabs tb, const u3
         kb = ws.k;
         zero8(C);
         gemm_rs<16, 2, true, 2>(C, ws, zb_val, side, zsink);
-        copy8(P, C);
+        copy8_acc(P, C);
     }
     kb = ws.k;
     lsave = 0;

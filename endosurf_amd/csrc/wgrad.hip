@@ -108,8 +108,8 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     // bias gradient = column sums of dA over the rows r with r % bias_stride == 0 (strides 1 or 4; stages start at multiples
     // of 16): taken from the staging registers on their way to LDS (thread tid holds columns 4*(tid&63).. of rows tid>>6 and
     // 8 + (tid>>6) of every stage), so the MFMA loop stays one branch-free basic block per stage
+    // (every thread sums the rows it stages; the row mask of a strided problem is applied once, in the epilogue)
     const bool do_bias = P.bias_out != nullptr && kb == 0;
-    const float bmask = (do_bias && (AF || ((tid >> 6) & (P.bias_stride - 1)) == 0)) ? 1.f : 0.f;       // AF: stride 1 only
     v4f_t bsum = {0.f, 0.f, 0.f, 0.f};
 
     // global -> register loads of one 16-row stage (two stages in flight: sets 0/1), register -> LDS stores.
@@ -118,26 +118,35 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
     const v4f vzero = {0.f, 0.f, 0.f, 0.f};
     const int fa1 = tid + WG_THREADS;
     // row-major operands: thread -> (row, 4 columns); offsets relative to the stage's first row
-    const size_t offA0 = (size_t)(tid >> 6) * P.lda + 4 * (tid & 63), offA1 = (size_t)(fa1 >> 6) * P.lda + 4 * (fa1 & 63);
+    // (32-bit lane offsets, applied as BYTE offsets to the stage's wave-uniform base pointer -- a stage spans 16 rows -- so that every
+    // load is "scalar base + 32-bit lane offset": as size_t element offsets they were 64-bit pairs, one of them reloaded from scratch in
+    // every stage of the loop at the 128-register cap)
+    const unsigned offA0 = (unsigned)(tid >> 6) * (unsigned)P.lda + 4u * (tid & 63);
     const int colB = kcol0 + 4 * (tid % (KW / 4));
-    const size_t offB = (size_t)(tid / (KW / 4)) * P.ldx + colB;
+    const unsigned offB = (unsigned)(tid / (KW / 4)) * (unsigned)P.ldx + (unsigned)colB;
     const bool okB = XF || colB < P.ldx;
     // fragment-ordered operands: unit u -> (wave block u>>8, ni, quad parity qq, lane) of the stage
     const int fqq = (tid >> 6) & 1, fni = (tid >> 7) & 1, fw = tid >> 8;                // fw in 0..1 (unit tid), +2 for unit tid+512
-    const size_t foffA0 = (size_t)(((fw * 16 + fni * 4 + fqq) * 64 + lane) * 4), foffA1 = foffA0 + (size_t)2 * 16 * 64 * 4;
-    const size_t foffB = (size_t)((((2 * kb + fw) * 16 + fni * 4 + fqq) * 64 + lane) * 4);
+    const unsigned foffA0 = (unsigned)(((fw * 16 + fni * 4 + fqq) * 64 + lane) * 4);
+    const unsigned foffB = (unsigned)((((2 * kb + fw) * 16 + fni * 4 + fqq) * 64 + lane) * 4);
     const int flrow = 8 * fqq + 4 * hi;                                                // first of the 4 local rows of the unit
     const int flcolA = 64 * fw + 32 * fni + lo, flcolB = 64 * fw + 32 * fni + lo;      // A: + 128 for the second unit
+    // the three byte offsets a thread applies to the stage's base pointers: laundered through an empty asm at every use, otherwise their
+    // zero-extensions are hoisted out of the stage loop as 64-bit pairs and the loads lose the scalar-base addressing form
+    const unsigned boffA0 = 4u * (AF ? foffA0 : offA0), boffB = 4u * (XF ? foffB : offB);
+    const size_t dA1 = AF ? (size_t)2 * 16 * 64 * 4 * 4 : (size_t)8 * P.lda * 4;      // bytes: unit tid + 512 = 8 rows (row-major) / 2 x 16 units (fragment order) further
     auto stage_ptr = [&](const float* base, int ld, bool frag, int m) {
         return frag ? base + (size_t)(m >> 6) * (64 * 256) + (size_t)((8 * ((m >> 5) & 1) + 2 * ((m >> 4) & 1)) * 256) : base + (size_t)m * ld;
     };
 #define WG_GLOAD(S, m)                                                                                \
     {                                                                                                 \
-        const float* pa = stage_ptr(P.dA, P.lda, AF, m);                                              \
-        S##a0 = *reinterpret_cast<const v4f*>(pa + (AF ? foffA0 : offA0));                            \
-        S##a1 = *reinterpret_cast<const v4f*>(pa + (AF ? foffA1 : offA1));                            \
-        const float* px = stage_ptr(P.X, P.ldx, XF, m);                                               \
-        S##b0 = okB ? *reinterpret_cast<const v4f*>(px + (XF ? foffB : offB)) : vzero;                \
+        const char* pa = reinterpret_cast<const char*>(stage_ptr(P.dA, P.lda, AF, m));                \
+        unsigned oa0 = boffA0, ob = boffB;                                                            \
+        asm volatile("" : "+v"(oa0), "+v"(ob));      /* keeps the zero-extension next to the load: see boffA0 */ \
+        S##a0 = *reinterpret_cast<const v4f*>(pa + oa0);                                              \
+        S##a1 = *reinterpret_cast<const v4f*>(pa + dA1 + oa0);      /* second unit: a wave-uniform distance away */ \
+        const char* px = reinterpret_cast<const char*>(stage_ptr(P.X, P.ldx, XF, m));                 \
+        S##b0 = okB ? *reinterpret_cast<const v4f*>(px + ob) : vzero;                                 \
     }
 #define WG_SSTORE(S, buf)                                                                             \
     {                                                                                                 \
@@ -145,12 +154,12 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
             float* la = Apan(buf) + flrow * 256 + flcolA;                                             \
             la[0] = S##a0[0]; la[256] = S##a0[1]; la[512] = S##a0[2]; la[768] = S##a0[3];             \
             la[128] = S##a1[0]; la[128 + 256] = S##a1[1]; la[128 + 512] = S##a1[2]; la[128 + 768] = S##a1[3]; \
-            bsum[0] += bmask * (S##a0[0] + S##a0[1] + S##a0[2] + S##a0[3]);                           \
-            bsum[1] += bmask * (S##a1[0] + S##a1[1] + S##a1[2] + S##a1[3]);                           \
+            bsum[0] += S##a0[0] + S##a0[1] + S##a0[2] + S##a0[3];                                     \
+            bsum[1] += S##a1[0] + S##a1[1] + S##a1[2] + S##a1[3];                                     \
         } else {                                                                                      \
             *reinterpret_cast<v4f*>(Apan(buf) + 4 * tid) = S##a0;                                     \
             *reinterpret_cast<v4f*>(Apan(buf) + 4 * fa1) = S##a1;                                     \
-            bsum += bmask * (S##a0 + S##a1);                                                          \
+            bsum += S##a0 + S##a1;                                                                    \
         }                                                                                             \
         if constexpr (XF) {                                                                           \
             float* lb = Bpan(buf) + flrow * KW + flcolB;                                              \
@@ -210,33 +219,40 @@ __device__ __forceinline__ void wgrad_task(const WgProb& P, int kb, int m0, int 
 #undef WG_GLOAD
 #undef WG_SSTORE
     // acc[t][tp][r]: n = nb*64 + 2*i + t, i = (r&3) + 8*(r>>2) + 4*hi ; k = kb*128 + kh*64 + 2*lo + tp
+    // The epilogue's lane indices are RE-DERIVED from the thread id (laundered through an empty asm so that they are new values): kept
+    // live across the stage loop they were what the allocator spilled at the 128-register cap of four waves per SIMD (round 4).
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, lo_e = lane_e & 31, hi_e = lane_e >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-            const int k = kcol0 + kh * 64 + 2 * lo + tp;
+            const int k = kcol0 + kh * 64 + 2 * lo_e + tp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + t;
+                const int n = nb * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hi_e) + t;
                 if constexpr (DET) det_tile[n * WG_KW + (k - kcol0)] = acc[t][tp][r];
                 else if (n < P.N && k < P.K) atomicAdd(P.out + (size_t)n * P.ldo + k, acc[t][tp][r]);
             }
         }
     if (do_bias) {      // workgroup-uniform: reduce the partial column sums through LDS (all stages consumed)
+        if (!AF && ((tid_e >> 6) & (P.bias_stride - 1)) != 0) bsum = v4f{0.f, 0.f, 0.f, 0.f};       // AF: stride 1 only
         __syncthreads();
         if constexpr (AF) {         // 4 threads (qq, hi) per column; unit tid holds column flcolA, unit tid+512 column flcolA + 128
-            lds[(fqq * 2 + hi) * 256 + flcolA] = bsum[0];
-            lds[(fqq * 2 + hi) * 256 + flcolA + 128] = bsum[1];
+            const int fqq_e = (tid_e >> 6) & 1, col_e = 64 * (tid_e >> 8) + 32 * ((tid_e >> 7) & 1) + lo_e;
+            lds[(fqq_e * 2 + hi_e) * 256 + col_e] = bsum[0];
+            lds[(fqq_e * 2 + hi_e) * 256 + col_e + 128] = bsum[1];
         } else {
-            *reinterpret_cast<v4f*>(lds + 4 * tid) = bsum;
+            *reinterpret_cast<v4f*>(lds + 4 * tid_e) = bsum;
         }
         __syncthreads();
-        if (tid < 256) {
+        if (tid_e < 256) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < (AF ? 4 : 8); ++r) s += lds[r * 256 + tid];
-            if constexpr (DET) det_bias[tid] = s;
-            else if (tid < P.N) atomicAdd(P.bias_out + tid, s);
+            for (int r = 0; r < (AF ? 4 : 8); ++r) s += lds[r * 256 + tid_e];
+            if constexpr (DET) det_bias[tid_e] = s;
+            else if (tid_e < P.N) atomicAdd(P.bias_out + tid_e, s);
         }
     }
     W_STAMP(9);

@@ -231,6 +231,21 @@ __device__ __forceinline__ void copy8(f32x16 (&P)[8], const f32x16 (&C)[8]) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) P[b] = C[b];
 }
+// copy8 with the copy PINNED to the accumulation registers (AGPR class, through an empty asm with an "a" operand).  A kernel that keeps
+// the previous layer's 128 values next to 128 live accumulators has 256 of its 512 registers in those two arrays; left to the
+// allocator, part of P is homed in the architectural half, which then has no room for the operand fragments (96 + 24 registers) and
+// whole 16-register accumulator tuples go to scratch (round 4: k_deform_vjp_x3r<SAVE> 57 -> 0 spilled registers).  P's elements are
+// read one at a time (v_accvgpr_read) where the next layer's operand is built.
+__device__ __forceinline__ void copy8_acc(f32x16 (&P)[8], const f32x16 (&C)[8]) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = C[b][r];
+            asm("" : "+a"(t));
+            P[b][r] = t;
+        }
+}
 
 // softplus'(z) = sigmoid(100 z) recovered from s = softplus(z): 1 - exp(-100 s), series where that cancels (chain_common.h
 // softplus100_grad_from_s on the raw exp unit).  The select is written as v_cmp + v_cndmask: left to the compiler, the ternary becomes a
@@ -273,16 +288,24 @@ struct RowTile {
     float* t;           // this wave's tile [32][XR_TILE_LD]
     int rowidx;         // this lane's row among the wave's 32 consecutive stack rows
     int hi, lane;
-    __device__ __forceinline__ void put(int s, const float (&v)[8], float* wave_base, int ld) const {      // wave_base = &stack[first row of the wave][0]
+    // Flush mapping: store i of a flush covers rows 4 (lane / 8) + i, 16-B chunk lane % 8 -- 8 complete 128-B lines per store, and the four
+    // stores of a flush (and the pairs of a whole layer) differ by compile-time byte offsets only (i LD 4 + 128 (s / 2) < 4096, the
+    // immediate field of a global store): ONE 32-bit lane offset against the wave-uniform base instead of four 64-bit addresses per lane
+    // (round 4: the address registers were what the saving kernels spilled).
+    template <int LD>
+    __device__ __forceinline__ void put(int s, const float (&v)[8], float* wave_base) const {      // wave_base = &stack[first row of the wave][0]
+        static_assert(3 * LD * 4 + 128 * 7 < 4096, "immediate offsets of the flush");
         float* p = t + rowidx * XR_TILE_LD + 16 * (s & 1) + 4 * hi;
         *reinterpret_cast<v4f_frag*>(p) = v4f_frag{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<v4f_frag*>(p + 8) = v4f_frag{v[4], v[5], v[6], v[7]};
         if (s & 1) {
+            const unsigned r = 4u * ((unsigned)lane >> 3), c = 4u * ((unsigned)lane & 7u);
+            const float* tp = t + r * XR_TILE_LD + c;
+            float* gp = wave_base + (r * (unsigned)LD + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
-                const v4f_frag x = *reinterpret_cast<const v4f_frag*>(t + r * XR_TILE_LD + c);
-                *reinterpret_cast<v4f_frag*>(wave_base + (size_t)r * ld + 32 * (s >> 1) + c) = x;
+                const v4f_frag x = *reinterpret_cast<const v4f_frag*>(tp + i * XR_TILE_LD);
+                *reinterpret_cast<v4f_frag*>(gp + i * LD + 32 * (s >> 1)) = x;
             }
         }
     }

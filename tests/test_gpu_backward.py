@@ -88,17 +88,18 @@ def _render_scalar(ret, c, dt, dev):
 
 
 FLOOR = 5e-3
-WIDER = {}          # (case, tensor) -> budget: tensors whose render-level gradient error exceeds FLOOR without the reference's own
-                    # fp32-vs-fp64 error (from 32 sampled entries) explaining it
+WIDER = {}          # (case, tensor) -> budget: none needed (round 4).  With the floor at 5e-3 (was 2e-2) the only tensors above it were
+                    # init_deform's colour layer 6 (bias, weight_v: 0.694 %), and the reference's OWN fp32-vs-fp64 error on those tensors is
+                    # 0.695 % (goldens: scalgraderr/*/rel, whole tensor) -- the 32 sampled entries had put it at 0.015 % / 0.19 %
 
 
 def _check_rows(rows, c, prefix64, prefix32, name, r=None):
     """Per parameter tensor, against the fp64 reference / oracle:
       (1) norm within 3x the reference's own fp32-vs-fp64 norm difference (golden norm summaries);
       (2) DIRECTION: relative L2 error of the whole tensor vs autograd on the fp64 oracle <= max(3x the reference's own
-          fp32-vs-fp64 relative error, FLOOR = 5e-3; round 4: was 2e-2) -- the reference's own error is estimated from the 32 sampled
-          entries per tensor the goldens hold for both of its precisions (grad64/*/val vs grad/*/val); tensors that need more than
-          the floor are listed by name in WIDER with the measured reason;
+          fp32-vs-fp64 relative error, FLOOR = 5e-3; round 4: was 2e-2) -- the reference's own error is the larger of its whole-tensor
+          figure (goldens ``{scalgrad,grad}err/<tensor>/rel``: the reference run in both precisions by tools/make_golden.py) and the
+          estimate from the 32 sampled entries per tensor the goldens hold for both precisions (grad64/*/val vs grad/*/val);
       (3) the same 32 sampled entries of the HIP gradient against the reference's fp64 values, same budget."""
     bad, table = {}, {}
     named = dict(r.named_parameters()) if r is not None else {}
@@ -117,6 +118,9 @@ def _check_rows(rows, c, prefix64, prefix32, name, r=None):
         samp_norm = np.linalg.norm(v64)
         # the reference's own relative error, from the sampled entries (scaled to the tensor: the samples' share of the norm varies)
         ref_rel = np.linalg.norm(v32 - v64) / (samp_norm + 1e-30) if samp_norm > 1e-3 * n64 * np.sqrt(len(idx) / max(len(idx), 1)) else 0.0
+        ekey = f"{prefix32}err/{k}/rel"
+        if ekey in c:
+            ref_rel = max(ref_rel, float(c[ekey]))
         budget = max(3 * ref_rel, WIDER.get((name, k), FLOOR))
         table[k] = (rel, budget, ref_rel)
         if rel > budget:

@@ -64,4 +64,4 @@ def test_graph_step_random_draws_and_recapture_on_a_new_shape():
     assert len(set(np.round(losses, 6))) == 6 and all(np.isfinite(losses))
     g0 = tr._graph["graph"]
     tr.train_step_graph(sc.batch(128), 7)
-    assert tr._graph["graph"] is None and tr._graph["shape"] == (128, 9) and g0 is not None
+    assert tr._graph["graph"] is None and tr._graph["key"][0] == (128, 9) and g0 is not None

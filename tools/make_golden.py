@@ -130,8 +130,13 @@ class patched_rng:
         torch.rand, torch.rand_like = self._rand, self._rand_like
 
 
-def run_reference(E, cfg, state, dtype, rays, tg, x, dd, tt, iter_step, u_perturb, u_neigh_full, scal_w, tag, out):
-    """Everything captured from one reference instance at one dtype; keys get suffix ``tag``."""
+def full_grads(named_params):
+    return {name: p.grad.detach().numpy().astype(np.float64).reshape(-1).copy() for name, p in named_params}
+
+
+def run_reference(E, cfg, state, dtype, rays, tg, x, dd, tt, iter_step, u_perturb, u_neigh_full, scal_w, tag, out, full=None):
+    """Everything captured from one reference instance at one dtype; keys get suffix ``tag``.  ``full`` (a dict) receives the complete
+    parameter gradients of the two scalars ("grad", "scalgrad"), kept by the caller only to form whole-tensor error summaries."""
     torch.set_default_dtype(dtype)
     r = build_ref(E, cfg, state)
     if dtype == torch.float64:
@@ -205,6 +210,8 @@ def run_reference(E, cfg, state, dtype, rays, tg, x, dd, tt, iter_step, u_pertur
                      surf_neig=sn).items():
         out[f"loss{tag}/{k}"] = npy(v) if torch.is_tensor(v) else np.array(v, np.float32)
     out.update({k.replace("grad/", f"grad{tag}/"): v for k, v in grad_summary(named_model_params(r)).items()})
+    if full is not None:
+        full["grad"] = full_grads(named_model_params(r))
 
     # ---- a render-only scalar with dense output weights (exercises every output) ----------------
     for p in r.parameters():
@@ -218,6 +225,8 @@ def run_reference(E, cfg, state, dtype, rays, tg, x, dd, tt, iter_step, u_pertur
     scal.backward()
     out[f"scal{tag}/value"] = npy(scal)
     out.update({k.replace("grad/", f"scalgrad{tag}/"): v for k, v in grad_summary(named_model_params(r)).items()})
+    if full is not None:
+        full["scalgrad"] = full_grads(named_model_params(r))
     torch.set_default_dtype(torch.float32)
     return float(loss), n_valid
 
@@ -253,8 +262,15 @@ def make_case(E, name, seed, mode, use_deform, n_rays, iter_step, perturb):
     out.update({"scal/cw": scal_w[0].numpy(), "scal/dw": scal_w[1].numpy(), "scal/gw": scal_w[2].numpy(),
                 "scal/ww": scal_w[3].numpy()})
     args = (rays, tg, x, dd, tt, iter_step, u_perturb, u_neigh, scal_w)
-    loss32, nv32 = run_reference(E, cfg, state, torch.float32, *args, "", out)       # the reference as shipped (fp32)
-    loss64, nv64 = run_reference(E, cfg, state, torch.float64, *args, "64", out)     # same code in fp64 = noise-free pin
+    f32, f64 = {}, {}
+    loss32, nv32 = run_reference(E, cfg, state, torch.float32, *args, "", out, f32)       # the reference as shipped (fp32)
+    loss64, nv64 = run_reference(E, cfg, state, torch.float64, *args, "64", out, f64)     # same code in fp64 = noise-free pin
+    # the reference's OWN fp32-vs-fp64 relative L2 error of every parameter-gradient tensor, over the WHOLE tensor (round 4): the 32
+    # sampled entries per tensor stored above can miss where that error sits (init_deform, colour layer 6: 0.015 % on the samples,
+    # 0.69 % on the tensor), and the render-level gradient tests budget the HIP result against 3x this number
+    for which in ("grad", "scalgrad"):
+        for pname, g64 in f64[which].items():
+            out[f"{which}err/{pname}/rel"] = np.array(np.linalg.norm(f32[which][pname] - g64) / (np.linalg.norm(g64) + 1e-300))
     # fp64 arrays are stored as float32 where that loses nothing relevant, to keep fixtures small
     for k in list(out):
         if out[k].dtype == np.float64 and out[k].size > 64:
