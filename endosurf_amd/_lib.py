@@ -25,7 +25,8 @@ class es_composite_args(C.Structure):
                 + [("N", C.c_int), ("S", C.c_int), ("sample_dist", C.c_float), ("cos_anneal", C.c_float)]
                 + [(n, C.c_void_p) for n in ("color", "depth", "weights", "cdf", "weight_max", "eik_acc", "wmax_idx",
                                              "g_color", "g_depth", "g_weights", "g_cdf", "g_wmax", "g_gradients_o", "g_eik",
-                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc", "ray_part", "cos_anneal_dev")])
+                                             "eik_den", "d_sdf", "d_go", "d_rgb", "d_invs_acc", "ray_part", "cos_anneal_dev",
+                                             "go_copy", "g_aux_sdf", "g_aux_go")] + [("n_aux", C.c_int)])
 
 
 class es_render_args(C.Structure):
@@ -37,7 +38,7 @@ class es_loss_args(C.Structure):
                                             "mask", "cmask", "valid_sn")]
                 + [("N", C.c_int)] + [(n, C.c_float) for n in ("w_color", "w_depth", "w_sdf", "w_angle", "w_eik", "w_sn")]
                 + [(n, C.c_void_p) for n in ("terms", "g_color", "g_depth", "g_eik", "g_aux_sdf", "g_aux_go", "den_out", "den_global")]
-                + [("world", C.c_float)])
+                + [("world", C.c_float), ("total_out", C.c_void_p)])
 
 
 _P = C.c_void_p
@@ -98,14 +99,17 @@ PROTOTYPES = {
     "es_adam_step": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_longlong, _P]),
     "es_train_schedule": (_I, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, C.c_double, _P, _P]),
     "es_adam_step_dev": (_I, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, _P, _P, C.c_longlong, _P]),
+    "es_zero": (_I, [_P, C.c_longlong, _P]),
+    "es_uniform": (_I, [_P, C.c_longlong, C.c_ulonglong, C.c_ulonglong, _P, _P]),
+    "es_scale": (_I, [_P, _P, C.c_longlong, _P, _P]),
+    "es_render_finish": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "es_timing_enable": (_I, [_I]),
     "es_timing_drain": (_I, [_I, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
-PF_X3_SDF = 64
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 
 _lib = None

@@ -37,6 +37,11 @@ int adam_step_dev(float* p, const float* g, float* m, float* v, long long n, flo
                   const float* g_extra, long long extra_index, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps, float step_size,
               float bc2_sqrt, float grad_scale, const float* g_extra, long long extra_index, hipStream_t st);
+int uniform(float* out, long long n, unsigned long long seed, unsigned long long subseq, const double* subseq_dev, hipStream_t st);
+int scale(float* out, const float* in, long long n, const float* s, hipStream_t st);
+int zero(void* p, long long nbytes, hipStream_t st);
+int render_finish(const float* eik_acc, const float* aux_sdf_ws, const float* aux_go_ws, int n_aux, float* eik, float* eik_den, float* aux_sdf,
+                  float* aux_go, hipStream_t st);
 static_assert(sizeof(es_loss_args) == sizeof(LossArgs), "es_loss_args must mirror es::LossArgs");
 int ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz, float* near_out,
               float* far_out, hipStream_t st);
@@ -189,6 +194,7 @@ int es_composite_forward(const es_composite_args* a, void* stream) {
 }
 int es_composite_backward(const es_composite_args* a, void* stream) {
     ES_REQUIRE(a && a->rays && a->z && a->sdf && a->g_o && a->rgb && a->variance, "es_composite_backward inputs");
+    ES_REQUIRE(a->n_aux >= 0, "es_composite_backward: negative n_aux");
     ES_REQUIRE(a->g_color && a->g_depth && a->g_eik && a->eik_den && a->d_sdf && a->d_go && a->d_rgb && a->d_invs_acc,
                "es_composite_backward adjoints");
     return composite(as_comp(a), 1, (hipStream_t)stream);
@@ -291,6 +297,24 @@ int es_train_loss(const es_loss_args* a, void* stream) {
     return train_loss(*reinterpret_cast<const LossArgs*>(a), (hipStream_t)stream);
 }
 
+int es_zero(void* p, long long nbytes, void* stream) {
+    ES_REQUIRE((p || nbytes == 0) && nbytes >= 0, "es_zero arguments");
+    return zero(p, nbytes, (hipStream_t)stream);
+}
+int es_uniform(float* out, long long n, unsigned long long seed, unsigned long long subsequence, const double* subsequence_dev, void* stream) {
+    ES_REQUIRE((out || n == 0) && n >= 0, "es_uniform arguments");
+    return uniform(out, n, seed, subsequence, subsequence_dev, (hipStream_t)stream);
+}
+int es_scale(float* out, const float* in, long long n, const float* s, void* stream) {
+    ES_REQUIRE(((out && in) || n == 0) && n >= 0 && s, "es_scale arguments");
+    return scale(out, in, n, s, (hipStream_t)stream);
+}
+int es_render_finish(const float* eik_acc, const float* aux_sdf_ws, const float* aux_go_ws, int n_aux, float* eik, float* eik_den, float* aux_sdf,
+                     float* aux_go, void* stream) {
+    ES_REQUIRE(eik_acc && eik && eik_den && n_aux >= 0 && (n_aux == 0 || (aux_sdf_ws && aux_go_ws && aux_sdf && aux_go)), "es_render_finish arguments");
+    return render_finish(eik_acc, aux_sdf_ws, aux_go_ws, n_aux, eik, eik_den, aux_sdf, aux_go, (hipStream_t)stream);
+}
+
 int es_train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
                         float* x, float* t, unsigned char* valid, void* stream) {
     ES_REQUIRE(rays && depth_gt && mask && d_i && u && x && t && valid && N >= 0, "es_train_aux_points buffers");
@@ -379,7 +403,7 @@ static int render_points(const es_render_args* a, PointSrc& ps, int& flags) {
                "es_render arguments");
     ps = PointSrc{};
     ps.rays = a->c.rays; ps.z = a->scratch; ps.mode = 1; ps.n_per_ray = a->c.S; ps.ldz = a->c.S; ps.M = a->c.N * a->c.S;
-    flags = (a->flags & (ES_PF_DEFORM | ES_PF_SAVE | ES_PF_X3 | ES_PF_X3_SDF)) | ES_PF_COLOR;      // ES_PF_X3: opt-in split-precision weight gradients
+    flags = (a->flags & (ES_PF_DEFORM | ES_PF_SAVE | ES_PF_X3)) | ES_PF_COLOR;      // ES_PF_X3: opt-in split-precision weight gradients
     return ST_OK;
 }
 static CompositeArgs render_composite_args(const es_render_args* a, int flags) {
@@ -388,6 +412,7 @@ static CompositeArgs render_composite_args(const es_render_args* a, int flags) {
     c.sdf = a->ws + L.off[WS_SDF]; c.g_o = a->ws + L.off[WS_GO]; c.rgb = a->ws + L.off[WS_RGB];
     const size_t P = (size_t)a->c.N * a->c.S;
     c.d_sdf = a->scratch + up64(P); c.d_go = c.d_sdf + up64(P); c.d_rgb = c.d_go + up64(3 * P);
+    c.n_aux = 0; c.g_aux_sdf = nullptr; c.g_aux_go = nullptr;      // (the whole-stage calls evaluate the ray samples only: scratch holds N*S rows)
     return c;
 }
 int es_render_forward(const es_render_args* a, const float* packed, const float* weff, void* stream) {

@@ -299,20 +299,20 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_deform_vjp_x3r(PointSrc src, 
 // WS_S_ACT as ROW-MAJOR [8][Mp][256] stacks while they are built and come back through a SIDE stream of the weight pipeline -- 2 direct
 // loads of 16 B per lane and k-step (per-lane source addresses: this lane's row) into their own ring of four k-steps, same barriers;
 // softplus' = 1 - exp(-100 s) as in the fp32 kernels; z_7 is still in registers when the sweep starts.
-// SAVE (training): additionally enc6(x_c) -> WS_S_S0, s_8 -> WS_S_ACT[7], the adjoints rho_7 .. rho_0 of the pre-activations ->
-// WS_S_RHO (row-major; the operands of the reverse GEMMs) and the adjoint of the encoding -> WS_S_ADJEPS: with this family's SDF
-// kernels the four [8][Mp][256] stacks of the SDF network are row-major (the fp32 family keeps them in fragment order; wgrad.hip takes
-// the layout per operand).
+// Inference only: the training chain keeps the SDF network on the fp32 kernels (point_fwd.hip / point_bwd.hip).  A saving variant of this
+// kernel and a split-precision SDF backward (tangent + reverse sweep as two kernels) existed in rounds 3-4 behind a default-off switch,
+// parity-tested and SLOWER than the fp32 kernels (2.24 ms against 1.60 for the backward): the SDF backward moves 6-7 KB per layer and
+// point and a lane-per-row kernel issues that traffic as 16-B pieces (2.0-2.5 TB/s) where the fp32 kernels' fragment-ordered tiles
+// reach 3 TB/s; the LDS tiles that would coalesce two more streams do not fit next to the weight ring.  Removed in round 4.
 constexpr int XS_ENC_LD = 41;       // floats per point row of the encoding / its adjoint (40 used; odd: conflict-free)
 constexpr int XS_ZRING_BYTES = XR_RING * 4 * 2048;
 constexpr int XS_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XS_ZRING_BYTES + (128 * XS_ENC_LD + 9 * 256 + 256 + 4) * 4;
 static_assert(XS_LDS_BYTES <= 160 * 1024, "LDS carve");
 __device__ __forceinline__ float sigmoid100(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-144.26950408889634f * z)); }
-template <bool DEFORM, bool COLOR, bool SAVE>
+template <bool DEFORM, bool COLOR>
 __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
                                                              float* __restrict__ ws_xc, float* __restrict__ ws_sdf, float* __restrict__ ws_feat,
-                                                             float* __restrict__ ws_gc, float* __restrict__ ws_go, float* __restrict__ SACT,
-                                                             float* __restrict__ S0, float* __restrict__ RHO, float* __restrict__ ADJEPS, int Mp) {
+                                                             float* __restrict__ ws_gc, float* __restrict__ ws_go, float* __restrict__ SACT, int Mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
     unsigned char* zring = ldsr + XR_RING * XR_CHUNK_BYTES;
     float* encs = reinterpret_cast<float*>(zring + XS_ZRING_BYTES);                // [128 points][41]: enc6(x_c), later its adjoint
@@ -353,10 +353,6 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     if (hi == 0) { erow[0] = x[0]; erow[1] = x[1]; erow[2] = x[2]; erow[39] = 0.f; }
     __syncthreads();
     const size_t lstride = (size_t)Mp * 256;
-    if (SAVE) {
-#pragma unroll
-        for (int k = 0; k < 20; k += 4) st4(S0 + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
-    }
     // logical k-steps: [0, 120) SF0 .. SF7, then (colour: SF8F,) SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0
     constexpr int KR0 = XR_SDF_FWD_CHUNKS + (COLOR ? 16 : 0);                       // first k-step of the reverse sweep
     WStream ws;
@@ -402,8 +398,7 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     // P = z_7
     if (COLOR) {       // geometry features = rows 1 .. 256 of the last layer
         init8(C, biasL + 8 * 256, hi);
-        float* S8 = (Sblk + (size_t)7 * lstride) + loff;
-        gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, act_val, side, [&](int s, const float (&v)[8]) { if (SAVE) st_kstep(S8, s, v); });
+        gemm_r<16, 2, false>(C, ws, act_val, side);
         float* fo = (ws_feat + blk0 * 256) + loff;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
@@ -413,19 +408,12 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     }
     {
         float s0 = 0.f;
-        float* S8 = (Sblk + (size_t)7 * lstride) + loff;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s4[4];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s4[i] = softplus100_native(P[b][4 * q + i]);
-                    s0 = fmaf(w8L[32 * b + 8 * q + 4 * hi + i], s4[i], s0);
-                }
-                if (SAVE && !COLOR) st4(S8 + 32 * b + 8 * q, s4[0], s4[1], s4[2], s4[3]);      // (with COLOR the feature GEMM's sink stored s_8)
-            }
+                for (int i = 0; i < 4; ++i) s0 = fmaf(w8L[32 * b + 8 * q + 4 * hi + i], softplus100_native(P[b][4 * q + i]), s0);
         s0 += __shfl_xor(s0, 32);
         if (hi == 0) ws_sdf[point] = s0 + w8L[256];
     }
@@ -437,14 +425,11 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
 #pragma unroll
                 for (int r = 0; r < 16; ++r) A[b][r] = 0.f;
     };
-    float* Rblk = RHO + blk0 * 256;
-    int lsave = 7;
-    const auto rsink = [&](int s, const float (&v)[8]) { if (SAVE) st_kstep((Rblk + lsave * lstride) + loff, s, v); };
     zero(C, 8);
-    gemm_rs<16, 2, false, (SAVE ? 2 : 0)>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
+    gemm_r<16, 2, false>(C, ws, [&](int s, int j) -> float {              // rho_7 = softplus'(z_7) . W8[0, :]
         const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
         return sigmoid100(P[b][4 * q + i]) * w8L[32 * b + 8 * q + 4 * hi + i];
-    }, side, rsink);
+    }, side);
     copy8_acc(P, C);
     int kb = 0;                                                  // first k-step of the running GEMM (its side-stream slots)
     const auto rho_val = [&](int s, int j) -> float {
@@ -467,11 +452,10 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
     };
 #pragma unroll 1
     for (int l = 6; l >= 1; --l) {
-        lsave = l;
         if (l == 4) {                                            // encoding part of the skip layer's input adjoint, same operand rho_4
             kb = ws.k;
             zero(E, 2);
-            gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);
+            gemm_r<16, 0, true>(E, ws, rho_val, side);
             park(false);
             kb = ws.k;
             zero(C, 8);
@@ -479,20 +463,15 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_fwd_x3r(PointSrc src, Tab
         } else {
             kb = ws.k;
             zero(C, 8);
-            gemm_rs<16, 2, true, (SAVE ? 2 : 0)>(C, ws, rho_val, side, rsink);
+            gemm_r<16, 2, true>(C, ws, rho_val, side);
         }
         copy8_acc(P, C);
     }
     kb = ws.k;
-    lsave = 0;
     zero(E, 2);
-    gemm_rs<16, 0, true, (SAVE ? 2 : 0)>(E, ws, rho_val, side, rsink);           // W_0^T rho_0
+    gemm_r<16, 0, true>(E, ws, rho_val, side);           // W_0^T rho_0
     park(true);
     // g_c[j] = sum_k adj[k] * d enc_k / d x_j   (a point's row is written and read by its own wave only: LDS operations of a wave are ordered)
-    if (SAVE) {      // (same wave: the LDS writes above are ordered before these reads; column 39 is the zero written at the start)
-#pragma unroll
-        for (int k = 0; k < 20; k += 4) st4(ADJEPS + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
-    }
     if (hi == 0) {
         // (x_c is read again here instead of living in three registers across both sweeps: ws_xc holds it -- written by the
         // deformation kernel, or by this lane at the top of the kernel)
@@ -666,14 +645,10 @@ static int infer_attrs() {
         if (int e = allow_big_lds(k_deform_jvp_x3r_tail, XI_LDS_BYTES > LEAN_LDS_BYTES ? XI_LDS_BYTES : LEAN_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<false>, XI_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_vjp_x3r<true>, XI_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false, false>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true, true>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false, true>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true, true>, XS_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<true, false>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, true>, XS_LDS_BYTES)) return e;
+        if (int e = allow_big_lds(k_sdf_fwd_x3r<false, false>, XS_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<true, false>, XC_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<false, false>, XC_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_fwd_x3r<true, true>, XC_LDS_BYTES)) return e;
@@ -723,7 +698,7 @@ int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff,
 }
 
 // all Mp points get sdf / g_c (/ g_o); the geometry features (color) are written for every point as well
-int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, bool save, hipStream_t st) {
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st) {
     if (int e = infer_attrs()) return e;
     const Tabs tb = make_tabs();
     ScopedTimer tm(KID_SDF_FWD_X3, src.M, st);
@@ -731,20 +706,9 @@ int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, fl
     const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
     float* xc = ws + L.off[WS_XC]; float* sdf = ws + L.off[WS_SDF]; float* feat = ws + L.off[WS_FEAT]; float* gc = ws + L.off[WS_GC];
     float* go = ws + L.off[WS_GO]; float* sact = ws + L.off[WS_S_ACT];
-    float* s0 = ws + L.off[WS_S_S0]; float* rho = ws + L.off[WS_S_RHO]; float* adj = ws + L.off[WS_S_ADJEPS];
-#define ES_LAUNCH_SDF_X3R(D, Cc, S) hipLaunchKernelGGL((k_sdf_fwd_x3r<D, Cc, S>), grid, block, XS_LDS_BYTES, st, src, tb, pk, weff, xc, sdf, feat, gc, go, sact, \
-                                                        s0, rho, adj, L.Mp)
-    const int v = (deform ? 4 : 0) | (color ? 2 : 0) | (save ? 1 : 0);
-    switch (v) {
-        case 0: ES_LAUNCH_SDF_X3R(false, false, false); break;
-        case 1: ES_LAUNCH_SDF_X3R(false, false, true); break;
-        case 2: ES_LAUNCH_SDF_X3R(false, true, false); break;
-        case 3: ES_LAUNCH_SDF_X3R(false, true, true); break;
-        case 4: ES_LAUNCH_SDF_X3R(true, false, false); break;
-        case 5: ES_LAUNCH_SDF_X3R(true, false, true); break;
-        case 6: ES_LAUNCH_SDF_X3R(true, true, false); break;
-        default: ES_LAUNCH_SDF_X3R(true, true, true); break;
-    }
+#define ES_LAUNCH_SDF_X3R(D, Cc) hipLaunchKernelGGL((k_sdf_fwd_x3r<D, Cc>), grid, block, XS_LDS_BYTES, st, src, tb, pk, weff, xc, sdf, feat, gc, go, sact, L.Mp)
+    if (deform) { if (color) ES_LAUNCH_SDF_X3R(true, true); else ES_LAUNCH_SDF_X3R(true, false); }
+    else { if (color) ES_LAUNCH_SDF_X3R(false, true); else ES_LAUNCH_SDF_X3R(false, false); }
 #undef ES_LAUNCH_SDF_X3R
     return hip_last("sdf_fwd_x3r");
 }

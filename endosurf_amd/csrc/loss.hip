@@ -72,6 +72,7 @@ __global__ __launch_bounds__(1024) void k_train_loss(LossArgs a) {
         a.terms[0] = lc; a.terms[1] = ld; a.terms[2] = ls; a.terms[3] = la; a.terms[4] = le; a.terms[5] = lsn;
         a.terms[6] = a.w_color * lc + a.w_depth * ld + a.w_sdf * ls + a.w_angle * la + a.w_eik * le + a.w_sn * lsn;
         a.terms[7] = sums[8];
+        if (a.total_out != nullptr) a.total_out[0] = a.terms[6];
         a.g_eik[0] = a.w_eik;
     }
     for (int i = tid; i < N; i += 1024) {

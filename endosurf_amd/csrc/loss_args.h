@@ -16,5 +16,6 @@ struct LossArgs {
     //   den_global[4]  use these (summed over the ranks) instead of the local sums, and scale every term and adjoint by ``world``: the mean
     //                  over the ranks of the per-rank loss / gradient is then the loss / gradient of the concatenated batch
     float* den_out; const float* den_global; float world;
+    float* total_out;      // nullable: the total once more, in storage of its own (the differentiable output of the autograd node)
 };
 }  // namespace es

@@ -69,8 +69,6 @@ int deform_tan_x3r(const PointSrc& src, const void* packed_r, const float* weff,
 int deform_bwd_x3r_with_tail(const BwdArgs& ba, const void* packed_r, int m_main, hipStream_t st);
 int color_bwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int m_color, const float* d_rgb,
                   hipStream_t st);
-int sdf_bwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, int m_color,
-                const float* d_sdf, const float* d_go, hipStream_t st);
 int deform_bwd_x3r(const void* packed_r, const float* weff, float* ws, const WsLayout& L, int M, int m_color, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
@@ -85,10 +83,10 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
     const bool deform = flags & PF_DEFORM;
     if (flags & PF_X3_CHAIN) {
         // the workspace comes from the split-precision training chain (point_fwd.hip): its backward on the register-resident core
-        // (train_x3r.hip): colour reverse sweep | deformation tangent sweep | SDF tangent + reverse sweeps | deformation reverse sweep
+        // (train_x3r.hip): colour reverse sweep | deformation tangent sweep | SDF backward (fp32 kernel) | deformation reverse sweep
         if (!packed_x3) return fail(ST_BAD_ARG, "point_backward_chains", "PF_X3_CHAIN needs the split weights (es_pack_x3)");
         const void* pr = packed_x3r_part(packed_x3);
-        if (deform && !(flags & PF_X3_SDF) && aux_tail(flags, a.M_color, src.M) && a.M_color % 128 == 0) {
+        if (deform && aux_tail(flags, a.M_color, src.M) && a.M_color % 128 == 0) {
             // the forward's tail arrangement (point_fwd.hip) mirrored: the tail on the fp32 family, its tangent + SDF-backward stages at the
             // head of this family's deformation reverse sweep (train_x3r.hip k_deform_bwd_x3r_tail):
             //   colour_bwd(main) | tan(main) | sdf_bwd(main, fp32) | [tan + sdf_bwd](tail, fp32) + deform_bwd(main) | deform_bwd(tail, fp32)
@@ -102,8 +100,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
         }
         if (flags & PF_COLOR) { if (int e = color_bwd_x3r(src, pr, weff, ws, a.L, deform, a.M_color, d_rgb, st)) return e; }
         if (deform) { if (int e = deform_tan_x3r(src, pr, weff, ws, a.L, d_go, st)) return e; }
-        if (flags & PF_X3_SDF) { if (int e = sdf_bwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, a.M_color, d_sdf, d_go, st)) return e; }
-        else { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_BWD, src.M, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
         if (deform) { if (int e = deform_bwd_x3r(pr, weff, ws, a.L, src.M, a.M_color, st)) return e; }
         return hip_last("point_backward_chains");
     }

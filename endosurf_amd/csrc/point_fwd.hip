@@ -62,7 +62,7 @@ static int launch_fwd(const FwdArgs& a, int n0, int t0, int n1, int t1, hipStrea
 int deform_jvp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st);
 int deform_vjp_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool save, hipStream_t st, int m_rows = 0);
 int deform_jvp_x3r_with_tail(const FwdArgs& fa, const void* packed_r, int m_main, hipStream_t st);
-int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, bool save, hipStream_t st);
+int sdf_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, hipStream_t st);
 int color_fwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, int Mcp, bool save, hipStream_t st);
 const void* packed_x3r_part(const void* packed_x3);
 
@@ -81,16 +81,16 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         // opt-in split-precision inference: deformation value + tangent | SDF value + features + reverse sweep | colour | VJP
         const void* pr = packed_x3r_part(packed_x3);
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, false, st)) return e; }
-        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, false, st)) return e;
+        if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, st)) return e;
         if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, false, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, false, st) : hip_last("point_forward");
     }
     if ((flags & PF_X3_CHAIN) && (flags & PF_SAVE) && packed_x3) {
         // opt-in split-precision TRAINING chain: all four launches on the register-resident core, keeping what the backward needs in
-        // the fp32 kernels' buffers (row-major stacks; the ReLU mask words and the SDF stacks' order are this family's: PF_X3_CHAIN
-        // tells the backward and the weight-gradient GEMMs)
+        // the fp32 kernels' buffers (row-major stacks; the ReLU mask words are this family's: PF_X3_CHAIN tells the backward); the SDF
+        // network stays on the fp32 kernels (see infer_x3r.hip)
         const void* pr = packed_x3r_part(packed_x3);
-        if (deform && !(flags & PF_X3_SDF) && aux_tail(flags, a.M_color, src.M) && a.M_color % 128 == 0) {
+        if (deform && aux_tail(flags, a.M_color, src.M) && a.M_color % 128 == 0) {
             // colour-less tail behind a block-aligned main part (the fused training batch): the tail goes through the fp32 family, its
             // dependent stages hidden in this family's 4-round launch (infer_x3r.hip k_deform_jvp_x3r_tail):
             //   deform(tail, fp32) | [sdf + vjp](tail, fp32) + jvp(main) | sdf(main, fp32) | colour(main) | vjp(main)
@@ -102,8 +102,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
             return deform_vjp_x3r(src, pr, weff, ws, a.L, true, st, Mc);
         }
         if (deform) { if (int e = deform_jvp_x3r(src, pr, weff, ws, a.L, true, st)) return e; }
-        if (flags & PF_X3_SDF) { if (int e = sdf_fwd_x3r(src, pr, weff, ws, a.L, deform, (flags & PF_COLOR) != 0, true, st)) return e; }
-        else { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, src.M, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mp / TM, 0, st)) return e; }
         if (flags & PF_COLOR) { if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mcp, true, st)) return e; }
         return deform ? deform_vjp_x3r(src, pr, weff, ws, a.L, true, st) : hip_last("point_forward");
     }

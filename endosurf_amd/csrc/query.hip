@@ -162,7 +162,8 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
 #ifdef ES_DEV_SWITCHES      // dev builds only (-DES_DEV_SWITCHES): A/B runs of the tile-height threshold
     static const int q16_max = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 8192;
 #else
-    constexpr int q16_max = 8192;         // batches up to here are latency-bound: 16-point tiles (query16.hip)
+    constexpr int q16_max = 9216;         // batches up to here are latency-bound: 16-point tiles (query16.hip); 8 192 = the up-sampling
+                                          // queries of 1 024 rays, + 1 024 = room for a secant iteration in the same grid (tools/front_end_times.py)
 #endif
     if (src.M > 0 && src.M <= q16_max && ld_out == 0 && ray_done == nullptr)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches

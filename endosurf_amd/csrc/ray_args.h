@@ -17,5 +17,10 @@ struct CompositeArgs {
     float* ray_part;
     // nullable: cos_anneal read from device memory instead (a captured training step changes it between replays)
     const float* cos_anneal_dev;
+    // nullable (round 4): forward -> an own-storage copy of the ray samples' g_o rows [N*S][3] (the renderer's ``gradients_o`` output);
+    // backward -> n_aux extra rows appended to d_sdf / d_go behind the N*S sample rows: the adjoints of the auxiliary points that were
+    // evaluated in the render's launches (NULL pointers = zero rows)
+    float* go_copy;
+    const float* g_aux_sdf; const float* g_aux_go; int n_aux;
 };
 }  // namespace es

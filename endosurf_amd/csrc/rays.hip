@@ -223,6 +223,14 @@ __device__ __forceinline__ float inv_s_from_variance(float var) { return fminf(f
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
+    if (BWD && a.n_aux > 0) {      // the auxiliary points' adjoint rows behind the samples' (one strided pass over the whole grid)
+        const size_t P = (size_t)a.N * a.S;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_aux; i += gridDim.x * 256) {
+            a.d_sdf[P + i] = a.g_aux_sdf ? a.g_aux_sdf[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.d_go[3 * (P + i) + k] = a.g_aux_go ? a.g_aux_go[3 * (size_t)i + k] : 0.f;
+        }
+    }
     const int ray = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (ray >= a.N) return;
     const RayGeom g = load_ray(a.rays, ray);
@@ -291,7 +299,13 @@ __global__ __launch_bounds__(256) void k_composite(CompositeArgs a) {
         for (int c = 0; c < CH; ++c)
             if (c < nchunk) {
                 const int s = c * 64 + lane;
-                if (s < S) { a.weights[(size_t)ray * S + s] = w[c]; a.cdf[(size_t)ray * S + s] = pcv[c]; }
+                if (s < S) {
+                    a.weights[(size_t)ray * S + s] = w[c]; a.cdf[(size_t)ray * S + s] = pcv[c];
+                    if (a.go_copy != nullptr) {
+                        const size_t p = (size_t)ray * S + s;
+                        a.go_copy[3 * p] = go[c][0]; a.go_copy[3 * p + 1] = go[c][1]; a.go_copy[3 * p + 2] = go[c][2];
+                    }
+                }
             }
         if (lane == 0) {
             a.color[3 * (size_t)ray + 0] = csum[0]; a.color[3 * (size_t)ray + 1] = csum[1]; a.color[3 * (size_t)ray + 2] = csum[2];

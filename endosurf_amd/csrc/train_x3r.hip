@@ -362,259 +362,6 @@ __global__ __launch_bounds__(XR_THREADS, 1) void k_color_bwd_x3r(PointSrc src, T
     }
 }
 
-// ---- SDF network backward: tangent sweep + reverse sweep ---------------------------------------------------------------------------
-// point_bwd.hip sdf_bwd_tile as two kernels (each keeps two accumulator sets, the fragments and one register-staged operand stream):
-//   k_sdf_tan_x3r   (i) forward tangent sweep along gbar_c -- the adjoint of the reverse-mode input gradient g_c is a forward-mode
-//                   directional derivative: tau_0 = (d enc6 / d x_c) gbar_c, pi_l = W_l tau_l, tau_{l+1} = phi'(z_l) pi_l, and the
-//                   second-order terms zeta_l = 100 (1 - phi'(z_l)) rho_l pi_l (softplus'' / softplus' = 100 (1 - softplus'));
-//                   tau_0 .. tau_8 -> WS_S_TAU0 / WS_S_TAU, zeta_0 .. zeta_7 -> WS_S_ZB
-//   k_sdf_rev_x3r   (ii) reverse sweep of the value pass seeded with [sdfbar | featbar]: zbar_l = phi'(z_l) sbar_{l+1} + zeta_l,
-//                   sbar_l = W_l^T zbar_l; zbar_0 .. zbar_7 overwrite WS_S_ZB; adjoint of x_c (enc6 adjoint + the encoding's own
-//                   second-order term + the colour network's) -> WS_XCBAR
-// phi'(z_l) comes from s_{l+1} (WS_S_ACT, a side stream of direct loads into LDS as in k_sdf_fwd_x3r); the second per-element operand
-// (rho_l / zeta_l / featbar) is staged through registers: two 16-B loads per lane and k-step, issued with the weight pipeline's loads
-// two k-steps ahead into four rotating register sets.  All stacks row-major (this family's SDF layout, see k_sdf_fwd_x3r).
-constexpr int XSB_LDS_BYTES = XR_RING * XR_CHUNK_BYTES + XR_RING * 4 * 2048 + (128 * 41 + 256 + 4) * 4;
-static_assert(XSB_LDS_BYTES <= 160 * 1024, "LDS carve");
-__device__ __forceinline__ void ld8(float (&r)[8], const float* p) {      // the two 16-B pieces of a k-step's operand in a row-major row (p holds + 4 hi)
-    const v4f_frag a = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(p));
-    const v4f_frag b = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(p + 8));
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-}
-
-__global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_tan_x3r(PointSrc src, Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ ws_xc,
-                                                             const float* __restrict__ gbar_main, const float* __restrict__ gbar_color, int M_color, int M,
-                                                             const float* __restrict__ SACT, const float* __restrict__ RHO, float* __restrict__ TAU0,
-                                                             float* __restrict__ TAU, float* __restrict__ ZB, int Mp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
-    unsigned char* sring = ldsr + XR_RING * XR_CHUNK_BYTES;
-    float* encs = reinterpret_cast<float*>(sring + XR_RING * 4 * 2048);            // [128 points][41]: tau_0
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, hi = lane >> 5;
-    const int point = blockIdx.x * 128 + wave * 32 + n;          // a workspace row (Mp is a multiple of 128)
-    float* erow = encs + (wave * 32 + n) * 41;
-    float x[3], g[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        x[c] = ws_xc[(size_t)point * 3 + c];
-        // gbar_c = J gbar_o from the deformation tangent sweep (or gbar_o itself without a deformation network) + the colour network's
-        g[c] = (point < M ? gbar_main[(size_t)point * 3 + c] : 0.f) + (point < M_color ? gbar_color[(size_t)point * 3 + c] : 0.f);
-    }
-#pragma unroll
-    for (int ii = 0; ii < 3; ++ii) {
-        const int i = 3 * hi + ii;
-        const float f = (float)(1 << i);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float s, co;
-            sincosf(x[c] * f, &s, &co);
-            erow[enc_index(3, i, 0, c)] = f * co * g[c];
-            erow[enc_index(3, i, 1, c)] = -f * s * g[c];
-        }
-    }
-    if (hi == 0) { erow[0] = g[0]; erow[1] = g[1]; erow[2] = g[2]; erow[39] = 0.f; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 20; k += 4) st4(TAU0 + (size_t)point * 64 + 20 * hi + k, erow[20 * hi + k], erow[20 * hi + k + 1], erow[20 * hi + k + 2], erow[20 * hi + k + 3]);
-    const size_t lstride = (size_t)Mp * 256;
-    const float* Srow = SACT + (size_t)point * 256 + 4 * hi;
-    const float* Rrow = RHO + (size_t)point * 256 + 4 * hi;
-    WStream ws;
-    ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane; ws.b0 = XR_SDF_CHUNK0;
-    ws.start();
-
-    // logical k-step kk -> (layer l = 1 .. 7 whose GEMM it belongs to, operand k-step s) or none (SF0, SF4A): SF0 [0, 4), l = 1 .. 4 at
-    // 4 + 16 (l - 1), SF4A [68, 72), l = 5 .. 7 at 72 + 16 (l - 5)
-    const auto where = [&](int kk, int& l, int& s) -> bool {
-        if (kk < 4 || (kk >= 68 && kk < 72) || kk >= 120) return false;
-        const int r = kk < 68 ? kk - 4 : kk - 8;
-        l = 1 + (r >> 4); s = r & 15;
-        return true;
-    };
-    float rb[4][8];                                               // rho_{l-1} of operand k-steps (set = k-step & 3)
-    const auto side = [&](int kk, int t, int sloc) {
-        int l, s;
-        if ((t != 1 && t != 4 && t != 2) || !where(kk, l, s)) return;
-        if (t == 2) { ld8(rb[sloc & 3], Rrow + (size_t)(l - 1) * lstride + 16 * s); return; }
-        const int piece = t == 4;
-        const float* srcp = Srow + (size_t)(l - 1) * lstride + 16 * s + 8 * piece;              // s_l = softplus(z_{l-1})
-        unsigned char* dst = sring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-    const auto enc_val = [&](int s, int j) -> float {
-        const int k = 16 * s + xr_kperm(hi, j);
-        return k < 39 ? erow[k] : 0.f;
-    };
-    f32x16 P[8], C[8];
-    zero8(C);
-    gemm_r<4>(C, ws, enc_val, side);                              // pi_0 (its k-steps 2, 3 stage the first two operand k-steps of layer 1)
-    copy8_acc(P, C);
-    int kb = 0;
-    float z2v[8];
-    float* Trow = TAU + (size_t)point * 256 + 4 * hi;
-    float* Zrow = ZB + (size_t)point * 256 + 4 * hi;
-    int lcur = 1;
-    const auto tau_val = [&](int s, int j) -> float {            // tau_l = phi'(z_{l-1}) pi_{l-1};  zeta_{l-1} alongside
-        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
-        const float sv = reinterpret_cast<const float*>(sring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
-        const float dphi = dphi_from_s(sv), pi = P[b][4 * q + i];
-        z2v[j] = 100.f * (1.f - dphi) * rb[s & 3][j] * pi;
-        return dphi * pi;
-    };
-    const auto tsink = [&](int s, const float (&v)[8]) {
-        st_kstep(Trow + (size_t)(lcur - 1) * lstride, s, v);
-        st_kstep(Zrow + (size_t)(lcur - 1) * lstride, s, z2v);
-    };
-#pragma unroll 1
-    for (int l = 1; l <= 7; ++l) {
-        lcur = l;
-        kb = ws.k;
-        zero8(C);
-        gemm_rs<16, 2, true, 4>(C, ws, tau_val, side, tsink);
-        if (l == 4) gemm_r<4>(C, ws, enc_val, side);              // NeRF skip: + W_4[:, 256:] tau_0
-        copy8_acc(P, C);
-    }
-    {   // tau_8 = phi'(z_7) pi_7 and zeta_7: no further GEMM (the tangent of the last layer is not needed)
-        const float* S8 = Srow + (size_t)7 * lstride;
-        const float* R7 = Rrow + (size_t)7 * lstride;
-        float* T8 = Trow + (size_t)7 * lstride;
-        float* Z7 = Zrow + (size_t)7 * lstride;
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f_frag sv = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(S8 + 32 * b + 8 * q));
-                const v4f_frag rv = __builtin_nontemporal_load(reinterpret_cast<const v4f_frag*>(R7 + 32 * b + 8 * q));
-                float t4[4], z4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dphi = dphi_from_s(sv[i]), pi = P[b][4 * q + i];
-                    t4[i] = dphi * pi;
-                    z4[i] = 100.f * (1.f - dphi) * rv[i] * pi;
-                }
-                st4(T8 + 32 * b + 8 * q, t4[0], t4[1], t4[2], t4[3]);
-                st4(Z7 + 32 * b + 8 * q, z4[0], z4[1], z4[2], z4[3]);
-            }
-    }
-}
-
-template <bool COLOR>
-__global__ __launch_bounds__(XR_THREADS, 1) void k_sdf_rev_x3r(Tabs tb, const u32x4* __restrict__ chunks, const float* __restrict__ weff,
-                                                             const float* __restrict__ ws_xc, const float* __restrict__ d_sdf, int M,
-                                                             const float* __restrict__ gbar_main, const float* __restrict__ gbar_color,
-                                                             const float* __restrict__ xcbar_color, const float* __restrict__ FBAR, int M_color,
-                                                             const float* __restrict__ SACT, float* __restrict__ ZB, const float* __restrict__ ADJEPS,
-                                                             float* __restrict__ xcbar, int Mp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsr[];
-    unsigned char* sring = ldsr + XR_RING * XR_CHUNK_BYTES;
-    float* encs = reinterpret_cast<float*>(sring + XR_RING * 4 * 2048);            // [128 points][41]: adjoint of the encoding
-    float* w8L = encs + 128 * 41;                                                  // [256] row 0 of the last layer
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, hi = lane >> 5;
-    const int point = blockIdx.x * 128 + wave * 32 + n;          // a workspace row (Mp is a multiple of 128)
-    float* erow = encs + (wave * 32 + n) * 41;
-    const bool colored = COLOR && point < M_color;
-    const float sb = point < M ? d_sdf[point] : 0.f;
-    for (int i = tid; i < 256; i += XR_THREADS) w8L[i] = weff[tb.woff[NET_S * LAYERS + 8] + i];
-    __syncthreads();
-    const size_t lstride = (size_t)Mp * 256;
-    const float* Srow = SACT + (size_t)point * 256 + 4 * hi;
-    float* Zrow = ZB + (size_t)point * 256 + 4 * hi;
-    const float* Frow = FBAR + (size_t)point * 256 + 4 * hi;
-    // logical k-steps: (COLOR: SR8F [0, 16),) then SR7 SR6 SR5 SR4A SR4M SR3 SR2 SR1 SR0; operand layer of GEMM gi: 7 6 5 4 4 3 2 1 0
-    constexpr int K0 = COLOR ? 16 : 0;
-    WStream ws;
-    ws.g = chunks; ws.ring = ldsr; ws.k = 0; ws.wave = wave; ws.lane = lane;
-    if (COLOR) { ws.e0 = 16; ws.b0 = XR_SR8F_CHUNK0; ws.b1 = XR_SI_CHUNK0 + 16; }
-    else ws.b0 = XR_SI_CHUNK0 + 16;
-    float rb[4][8];                                               // featbar / zeta_l of operand k-steps (set = k-step & 3)
-    const auto side = [&](int kk, int t, int sloc) {
-        if (t != 1 && t != 4 && t != 2) return;
-        if (kk < K0) {                                            // SR8F: the operand is featbar itself (registers only)
-            if (t == 2) ld8(rb[sloc & 3], Frow + 16 * kk);
-            return;
-        }
-        const int r = kk - K0;
-        if (r >= 9 * 16) return;
-        const int gi = r >> 4, s = r & 15, layer = gi <= 3 ? 7 - gi : 8 - gi;
-        if (t == 2) { ld8(rb[sloc & 3], Zrow + (size_t)layer * lstride + 16 * s); return; }
-        const int piece = t == 4;
-        const float* srcp = Srow + (size_t)layer * lstride + 16 * s + 8 * piece;                 // s_{layer+1} = softplus(z_layer)
-        unsigned char* dst = sring + (((kk & (XR_RING - 1)) * 4 + wave) * 2 + piece) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-    // the loads of the first two k-steps (the weight pipeline's start() stages its own): issued before it, landed at its barrier
-    side(0, 1, 0); side(0, 4, 0); side(0, 2, 0); side(1, 1, 1); side(1, 4, 1); side(1, 2, 1);
-    ws.start();
-
-    f32x16 P[8], C[8];
-    zero8(C);
-    if (COLOR) {       // adjoint of s_8 from the feature rows: W_8[1:, :]^T featbar
-        gemm_r<16, 2, true>(C, ws, [&](int s, int j) -> float { return colored ? rb[s & 3][j] : 0.f; }, side);
-    }
-#pragma unroll
-    for (int b = 0; b < 8; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[b][r] = C[b][r] + sb * w8L[32 * b + 8 * (r >> 2) + 4 * hi + (r & 3)];      // + sdfbar W_8[0, :]
-    int kb = 0;
-    int lsave = 7;
-    const auto zb_val = [&](int s, int j) -> float {             // zbar_l = phi'(z_l) sbar_{l+1} + zeta_l
-        const int b = s >> 1, q = 2 * (s & 1) + (j >> 2), i = j & 3;
-        const float sv = reinterpret_cast<const float*>(sring + ((((kb + s) & (XR_RING - 1)) * 4 + wave) * 2 + (j >> 2)) * 1024)[lane * 4 + i];
-        return fmaf(dphi_from_s(sv), P[b][4 * q + i], rb[s & 3][j]);
-    };
-    const auto zsink = [&](int s, const float (&v)[8]) { st_kstep(Zrow + (size_t)lsave * lstride, s, v); };
-    f32x16 E[8];                                                 // adjoint of the encoding input (blocks 0, 1): skip part + layer 0
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) E[b][r] = 0.f;
-#pragma unroll 1
-    for (int l = 7; l >= 1; --l) {
-        lsave = l;
-        if (l == 4) {      // encoding part of the skip layer's input adjoint first (same operand zbar_4; only the second GEMM stores it:
-            kb = ws.k;     // the first one's operand build still needs zeta_4 where zbar_4 goes)
-            gemm_r<16, 0, true>(E, ws, zb_val, side);
-        }
-        kb = ws.k;
-        zero8(C);
-        gemm_rs<16, 2, true, 2>(C, ws, zb_val, side, zsink);
-        copy8_acc(P, C);
-    }
-    kb = ws.k;
-    lsave = 0;
-    gemm_rs<16, 0, true, 2>(E, ws, zb_val, side, zsink);            // += W_0^T zbar_0
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * b + 8 * (r >> 2) + 4 * hi + (r & 3);
-            if (f < 39) erow[f] = E[b][r];
-        }
-    if (hi == 0) {      // (same wave: the LDS writes above are ordered before these reads)
-        const float* AE = ADJEPS + (size_t)point * 64;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float xj = ws_xc[(size_t)point * 3 + j];
-            const float gb = (point < M ? gbar_main[(size_t)point * 3 + j] : 0.f) + (colored ? gbar_color[(size_t)point * 3 + j] : 0.f);
-            float gv = erow[j], h = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const float f = (float)(1 << i);
-                float s, co;
-                sincosf(xj * f, &s, &co);
-                gv += f * (erow[enc_index(3, i, 0, j)] * co - erow[enc_index(3, i, 1, j)] * s);
-                // second-order encoding term: sum_k adj_eps[k] d2 enc_k / d x_j^2 gbar_c[j]
-                h -= f * f * (AE[enc_index(3, i, 0, j)] * s + AE[enc_index(3, i, 1, j)] * co);
-            }
-            xcbar[(size_t)point * 3 + j] = gv + h * gb + (colored ? xcbar_color[(size_t)point * 3 + j] : 0.f);
-        }
-    }
-}
-
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 static int train_attrs() {
     static DeviceOnce attr_done;
@@ -622,9 +369,6 @@ static int train_attrs() {
         if (int e = allow_big_lds(k_deform_tan_x3r, XT_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_bwd_x3r, XT_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_deform_bwd_x3r_tail, XT_LDS_BYTES > LEAN_LDS_BYTES ? XT_LDS_BYTES : LEAN_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_tan_x3r, XSB_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_rev_x3r<true>, XSB_LDS_BYTES)) return e;
-        if (int e = allow_big_lds(k_sdf_rev_x3r<false>, XSB_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_bwd_x3r<true>, XCB_LDS_BYTES)) return e;
         if (int e = allow_big_lds(k_color_bwd_x3r<false>, XCB_LDS_BYTES)) return e;
         attr_done.done();
@@ -658,27 +402,6 @@ int deform_bwd_x3r(const void* packed_r, const float* weff, float* ws, const WsL
                        ws + L.off[WS_XCBAR], ws + L.off[WS_VBAR_C], m_color, reinterpret_cast<const u32x4*>(ws + L.off[WS_D_MASK]),
                        ws + L.off[WS_D_A], ws + L.off[WS_D_A8], L.Mp);
     return hip_last("deform_bwd_x3r");
-}
-
-// SDF network backward of all Mp points (tangent sweep, then reverse sweep); d_go is the adjoint of g_o = g_c without a deformation network
-int sdf_bwd_x3r(const PointSrc& src, const void* packed_r, const float* weff, float* ws, const WsLayout& L, bool deform, bool color, int m_color,
-                const float* d_sdf, const float* d_go, hipStream_t st) {
-    if (int e = train_attrs()) return e;
-    const Tabs tb = make_tabs();
-    ScopedTimer tm(KID_SDF_BWD_X3, src.M, st);
-    const dim3 grid(L.Mp / 128), block(XR_THREADS);
-    const u32x4* pk = reinterpret_cast<const u32x4*>(packed_r);
-    const float* gmain = deform ? ws + L.off[WS_JU] : d_go;
-    const int Mmain = deform ? L.Mp : src.M;                      // WS_JU has a row for every workspace row, d_go only M
-    const int mc = color ? m_color : 0;
-    hipLaunchKernelGGL(k_sdf_tan_x3r, grid, block, XSB_LDS_BYTES, st, src, tb, pk, ws + L.off[WS_XC], gmain, ws + L.off[WS_GCBAR_C], mc, Mmain,
-                       ws + L.off[WS_S_ACT], ws + L.off[WS_S_RHO], ws + L.off[WS_S_TAU0], ws + L.off[WS_S_TAU], ws + L.off[WS_S_ZB], L.Mp);
-#define ES_LAUNCH_SREV(Cc) hipLaunchKernelGGL(k_sdf_rev_x3r<Cc>, grid, block, XSB_LDS_BYTES, st, tb, pk, weff, ws + L.off[WS_XC], d_sdf, src.M, gmain,            \
-        ws + L.off[WS_GCBAR_C], ws + L.off[WS_XCBAR_C], ws + L.off[WS_FEATBAR], mc, ws + L.off[WS_S_ACT], ws + L.off[WS_S_ZB], ws + L.off[WS_S_ADJEPS], \
-        ws + L.off[WS_XCBAR], L.Mp)
-    if (color) ES_LAUNCH_SREV(true); else ES_LAUNCH_SREV(false);
-#undef ES_LAUNCH_SREV
-    return hip_last("sdf_bwd_x3r");
 }
 
 // reverse sweep of the colour network over the whole 128-point blocks that cover [0, m_color)

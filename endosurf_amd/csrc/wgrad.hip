@@ -864,9 +864,9 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         if (int e = launch_group(g, n, sm, 0, x3 ? KID_WGRAD_D_X3 : KID_WGRAD_D, M, det, x3, st)) return e;
     }
     {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
-        // kernels (s, rho, tau, zbar) are fragment-ordered when the fp32 kernels wrote them (their epilogues load AND store them: one
-        // dwordx4 per quad) and row-major when the split-precision family's SDF kernels did (PF_X3_CHAIN | PF_X3_SDF, infer_x3r.hip / train_x3r.hip)
-        const int fr = ((flags & PF_X3_CHAIN) && (flags & PF_X3_SDF)) ? 0 : 1;
+        // kernels (s, rho, tau, zbar) are fragment-ordered: the fp32 SDF kernels, which write them in both kernel families, load AND
+        // store them in their epilogues (one dwordx4 per quad); the operand-layout flag stays a per-problem property
+        const int fr = 1;
         n = 0;
         add(B(WS_S_S0), 64, B(WS_S_ZB), 256, Mp, 39, 256, dW(NET_S, 0), 39, dB(NET_S, 0), 1, 0, fr);
         add(B(WS_S_TAU0), 64, B(WS_S_RHO), 256, Mp, 39, 256, dW(NET_S, 0), 39, nullptr, 1, 0, fr);

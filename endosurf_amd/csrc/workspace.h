@@ -19,7 +19,6 @@ constexpr int PF_COLOR = 2;    // evaluate the colour network (render_core) — 
 constexpr int PF_SAVE = 4;     // keep activations for the backward pass (training)
 constexpr int PF_X3_CHAIN = 32; // OPT-IN: the workspace belongs to the split-precision TRAINING chain (infer_x3r.hip with SAVE / train_x3r.hip): its
                                 // ReLU mask words are in that family's layout, so the backward must run that family's kernels.  No effect on offsets
-constexpr int PF_X3_SDF = 64;   // with PF_X3_CHAIN: the SDF network's training kernels of that family as well (row-major SDF stacks); default: fp32 SDF kernels
 constexpr int PF_RAW_DIR = 16;  // colour-only evaluation on explicit inputs (es_color_forward): the view direction is used as given, not normalised
 constexpr int PF_X3 = 8;       // OPT-IN: weight-gradient GEMMs in split precision (3 x bf16 planes, wgrad.hip); no effect on layouts
 

@@ -14,9 +14,7 @@ constexpr int XR_SEGS[] = {DF0, DF1, DF2, DF3, DF4, DF5, DF6, DF7, SF0, SF1, SF2
                            SF8F, SR7, SR6, SR5, SR4A, SR4M, SR3, SR2, SR1, SR0,
                            CF0S, CF0F, CF1, CF2, CF3, CF4H, CF4S, CF4F, CF5, CF6, CF7,
                            // [46, 57) colour reverse sweep (train_x3r.hip): the three parts of the skip layer's input adjoint read the same operand
-                           CR7, CR6, CR5, CR4F, CR4S, CR4H, CR3, CR2, CR1, CR0F, CR0S,
-                           // [57] feature rows of the SDF network's last layer, reverse (seed of the SDF backward's reverse sweep)
-                           SR8F};
+                           CR7, CR6, CR5, CR4F, CR4S, CR4H, CR3, CR2, CR1, CR0F, CR0S};
 constexpr int XR_COUNT = sizeof(XR_SEGS) / sizeof(int);
 constexpr int xr_kg(int i) { return 2 * cdiv(SEGS[XR_SEGS[i]].kreal, 32); }      // k-steps, even (the stream works in pairs)
 constexpr int xr_chunk0(int i) {
@@ -32,7 +30,6 @@ constexpr int XR_DR_CHUNK0 = xr_chunk0(17);               // first k-step of DR7
 constexpr int XR_SI_CHUNK0 = xr_chunk0(25);               // first k-step of SF8F (then SR7 ...)
 constexpr int XR_C_CHUNK0 = xr_chunk0(35);                // first k-step of CF0S
 constexpr int XR_CR_CHUNK0 = xr_chunk0(46);               // first k-step of CR7
-constexpr int XR_SR8F_CHUNK0 = xr_chunk0(57);             // first k-step of SR8F
 constexpr int XR_SDF_FWD_CHUNKS = XR_QUERY_CHUNKS - XR_SDF_CHUNK0;      // 120 k-steps of SF0 .. SF7
 constexpr int XR_CHUNK_UNITS = 8 * 3;                     // 1 KB units (64 lanes x 16 B) per k-step
 constexpr int XR_CHUNK_BYTES = XR_CHUNK_UNITS * 1024;
@@ -40,7 +37,7 @@ constexpr int XR_THREADS = 256;
 constexpr int XR_ENC_LD = 68;                             // floats per column row of the encoding scratch (conflict-free b32 / b128 reads)
 constexpr int XR_RING = 4;                                // k-steps resident in LDS
 static_assert(XR_SDF_CHUNK0 % 2 == 0 && XR_DR_CHUNK0 % 2 == 0 && XR_SI_CHUNK0 % 2 == 0 && XR_C_CHUNK0 % 2 == 0 && XR_CHUNKS % 2 == 0, "k-step pairs");
-static_assert(XR_SEGS[46] == CR7 && XR_SEGS[56] == CR0S && XR_SEGS[57] == SR8F && XR_COUNT == 58, "segment order the training kernels hard-code");
+static_assert(XR_SEGS[46] == CR7 && XR_SEGS[56] == CR0S && XR_COUNT == 57, "segment order the training kernels hard-code");
 static_assert(LAYER_N[NET_D][3] == 204 && LAYER_N[NET_S][7] == 256 && SEGS[SF4A].kreal == 39, "shapes the kernels hard-code");
 
 // position j (0..7) of lane half hi in k-step-local order -> k offset inside the 16-wide step

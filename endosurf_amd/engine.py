@@ -54,8 +54,11 @@ class Engine:
         # split-precision mode: grad-enabled evaluations run the split-precision TRAINING chain (infer_x3r.hip with saves +
         # train_x3r.hip); False keeps the fp32 chain kernels under the split-precision queries / weight gradients (round-2 behaviour)
         self.x3_train_chain = True
-        # ... including the SDF network's training kernels (experimental: parity-tested, but slower than the fp32 SDF kernels)
-        self.x3_sdf_chain = os.environ.get("ES_X3_SDF", "0") not in ("0", "", "false", "False")
+        # (the SDF network stays on the fp32 kernels in the training chain: csrc/infer_x3r.hip)
+        # step arena (round 4): inside Trainer's step ``zeros`` hands out slices of ONE buffer that one memset cleared (arena_begin)
+        self._arena, self._arena_off, self._arena_on = None, 0, False
+        self._ones1 = None
+        self._rng_calls = 0
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -79,14 +82,60 @@ class Engine:
         return torch.empty(*shape, device=self.device, dtype=dtype)
 
     def zeros(self, *shape, dtype=torch.float32):
+        if self._arena_on and dtype == torch.float32:
+            shp = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+            n = 1
+            for s in shp:
+                n *= int(s)
+            off = self._arena_off
+            if 0 < n and off + n <= self._arena.numel():
+                self._arena_off = off + (n + 63) // 64 * 64          # 256-byte aligned slices
+                return self._arena[off:off + n].view(shp)
         return torch.zeros(*shape, device=self.device, dtype=dtype)
+
+    # ---- step arena / step plumbing (csrc/step.hip) --------------------------------------------------
+    def arena_begin(self, extra_floats: int = 0):
+        """Start of a training step: every ``zeros`` until ``arena_end`` is a slice of one buffer cleared by ONE memset (the eikonal
+        sums, the inv_s adjoint, the effective-weight and parameter gradient buffers, the marching scratch ...) instead of a fill
+        launch each.  The slices are valid until the next ``arena_begin`` (the flat gradient of a step lives here: it is consumed by the
+        optimiser within the step; ``.grad`` views read as zeros once the next step has begun)."""
+        need = self.n_weff + self.n_param + 4096 + int(extra_floats) + 64 * 32
+        need = (need + 4095) // 4096 * 4096          # (a 16-KB multiple: the runtime clears it with one fill kernel, not body + remainder)
+        if self._arena is None or self._arena.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.EndoSurfHipError("the step arena must exist before a step is captured (run one eager step first)")
+            self._arena = self.empty(need)
+        check(self.lib.es_zero(ptr(self._arena), 4 * self._arena.numel(), self.st()), "es_zero")
+        self._arena_off, self._arena_on = 0, True
+
+    def arena_end(self):
+        self._arena_on = False
+
+    @property
+    def ones1(self) -> torch.Tensor:
+        """A persistent device [1] holding 1.0: the seed of a step's backward pass (``loss.backward(gradient=...)``: no fill launch, and
+        the loss node recognises it by address and hands its adjoints on unscaled)."""
+        if self._ones1 is None:
+            self._ones1 = torch.ones(1, device=self.device)
+        return self._ones1
+
+    def uniform(self, n: int, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """n uniform draws in [0, 1) in ONE launch (Philox4x32-10 keyed by torch's seed; one subsequence per call, plus -- inside a
+        captured step -- the device-resident step counter, so that replays draw new numbers)."""
+        out = self.empty(int(n))
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        sub = self._rng_calls
+        if not torch.cuda.is_current_stream_capturing():
+            self._rng_calls += 1
+        check(self.lib.es_uniform(ptr(out), int(n), seed, sub, ptr(step_dev) if step_dev is not None else None, self.st()), "es_uniform")
+        return out
 
     # ---- weights ----------------------------------------------------------------------------------
     def weightnorm_pack(self, flat_params: torch.Tensor, use_deform: bool):
         weff = self.empty(self.n_weff)
         packed = self.empty(self.n_packed)
         if not use_deform:
-            weff.zero_()
+            check(self.lib.es_zero(ptr(weff), 4 * weff.numel(), self.st()), "es_zero")
         check(self.lib.es_weightnorm_pack(ptr(flat_params), ptr(weff), ptr(packed), int(use_deform), self.st()), "es_weightnorm_pack")
         return weff, packed
 
@@ -234,24 +283,33 @@ class Engine:
             a._keep.append(part)
         return a
 
-    def composite_forward(self, a: es_composite_args, eik_acc=None):
-        """``eik_acc`` [2] (optional): accumulate the eikonal sums into an existing buffer (chunked renders)."""
+    def composite_forward(self, a: es_composite_args, eik_acc=None, go_copy: bool = False):
+        """``eik_acc`` [2] (optional): accumulate the eikonal sums into an existing buffer (chunked renders).  ``go_copy``: the kernel
+        also writes the samples' g_o rows into storage of their own (out["go"] [N,S,3]: the renderer's ``gradients_o``)."""
         N, S = a.N, a.S
         out = dict(color=self.empty(N, 3), depth=self.empty(N, 1), weights=self.empty(N, S), cdf=self.empty(N, S),
                    weight_max=self.empty(N, 1), eik_acc=eik_acc if eik_acc is not None else self.zeros(2),
                    wmax_idx=self.empty(N, dtype=torch.int32))
         for k, v in out.items():
             setattr(a, k, ptr(v))
+        if go_copy:
+            out["go"] = self.empty(N, S, 3)
+            a.go_copy = ptr(out["go"])
         a._keep.append(out)
         check(self.lib.es_composite_forward(C.byref(a), self.st()), "es_composite_forward")
         return out
 
     def composite_backward(self, a: es_composite_args, g_color, g_depth, g_eik, eik_den, g_weights=None, g_cdf=None, g_wmax=None,
-                           g_gradients_o=None, d_invs_acc=None):
+                           g_gradients_o=None, d_invs_acc=None, n_aux: int = 0, g_aux_sdf=None, g_aux_go=None):
+        """``n_aux`` > 0: d_sdf / d_go get n_aux extra rows behind the N*S sample rows, filled by the same launch with the auxiliary
+        points' adjoints (None = zeros): the row order of the fused point evaluation, no concatenation."""
         N, S = a.N, a.S
-        out = dict(d_sdf=self.empty(N * S), d_go=self.empty(N * S, 3), d_rgb=self.empty(N * S, 3),
+        out = dict(d_sdf=self.empty(N * S + n_aux), d_go=self.empty(N * S + n_aux, 3), d_rgb=self.empty(N * S, 3),
                    d_invs_acc=d_invs_acc if d_invs_acc is not None else self.zeros(1))
-        keep = [g_color, g_depth, g_eik, eik_den, g_weights, g_cdf, g_wmax, g_gradients_o]
+        keep = [g_color, g_depth, g_eik, eik_den, g_weights, g_cdf, g_wmax, g_gradients_o, g_aux_sdf, g_aux_go]
+        a.n_aux = int(n_aux)
+        a.g_aux_sdf = ptr(g_aux_sdf) if (n_aux and g_aux_sdf is not None) else None
+        a.g_aux_go = ptr(g_aux_go) if (n_aux and g_aux_go is not None) else None
         a.g_color, a.g_depth, a.g_eik, a.eik_den = ptr(g_color), ptr(g_depth), ptr(g_eik), ptr(eik_den)
         a.g_weights = ptr(g_weights) if g_weights is not None else None
         a.g_cdf = ptr(g_cdf) if g_cdf is not None else None
@@ -353,9 +411,6 @@ def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> Poi
         # opt-in: the launches of a large evaluation in split precision -- csrc/infer_x3r.hip without PF_SAVE; with PF_SAVE the
         # split-precision TRAINING chain, whose workspace must go through es_point_backward_x3 (``ctx.x3_chain``)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
-        if save and self.x3_sdf_chain:
-            flags |= _lib.PF_X3_SDF
-            ctx.flags = flags            # no effect on the layout's offsets; the backward reads the family from it
         check(self.lib.es_point_forward_x3(C.byref(pts), ptr(packed), ptr(px3), ptr(weff), ptr(ctx.ws), flags, int(m_color),
                                            self.st()), "es_point_forward_x3")
         ctx.x3_chain = save

@@ -379,6 +379,7 @@ class _PackFn(torch.autograd.Function):
         ctx.model_ref, ctx.eng, ctx.flat, ctx.use_deform = model_ref, eng, model._flat, model.use_deform
         ctx.slots = [(model._layout[key][0], p.numel(), tuple(p.shape)) for key, p in model.ordered_params()]
         ctx.mark_non_differentiable(packed)
+        ctx.set_materialize_grads(False)      # (otherwise autograd zero-fills a 17 MB adjoint for ``packed`` at every backward)
         return weff, packed
 
     @staticmethod
@@ -386,6 +387,8 @@ class _PackFn(torch.autograd.Function):
         model = ctx.model_ref()
         if model is not None:
             model._pack_cache = None
+        if dweff is None:
+            return (None, None, *[None for _ in ctx.slots])
         dflat = ctx.eng.weightnorm_backward(ctx.flat, dweff.contiguous(), ctx.use_deform)
         if model is not None:
             model._flat_grad = dflat          # the parameters' .grad are views of this buffer (used by trainer.FlatAdam)
@@ -483,17 +486,22 @@ class _RenderFn(torch.autograd.Function):
         pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR, m_color=P_ if fused else 0)
         sdf_all, go_all = pctx.view("sdf"), pctx.view("go")
         a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
-        out = eng.composite_forward(a)
-        eik_den = (out["eik_acc"][1] + 1e-6).reshape(1)      # the eikonal term's normaliser (exact data-parallel mode reads it from the outputs)
-        eik = out["eik_acc"][0] / eik_den[0]
+        # own storage for every output (the 6.7 GB workspace must not outlive the backward): the compositing launch writes the samples'
+        # g_o rows a second time, es_render_finish forms gradient_o_error and its normaliser from the two batch sums and copies the
+        # auxiliary rows -- one launch where there were three clones, an add and a divide
+        out = eng.composite_forward(a, go_copy=True)
+        n_aux = aux_x.shape[0] if fused else 0
+        eik, den2 = eng.empty(1), eng.empty(2)
+        aux_sdf, aux_go = eng.empty(n_aux, 1), eng.empty(n_aux, 3)
+        _lib.check(eng.lib.es_render_finish(_lib.ptr(out["eik_acc"]), _lib.ptr(sdf_all[P_:]) if n_aux else None, _lib.ptr(go_all[P_:]) if n_aux else None,
+                                            n_aux, _lib.ptr(eik), _lib.ptr(den2), _lib.ptr(aux_sdf) if n_aux else None,
+                                            _lib.ptr(aux_go) if n_aux else None, eng.st()), "es_render_finish")
+        eik_den, den_out = den2[0:1], den2[1:2]      # the eikonal term's normaliser: kept for the backward / handed out (exact data-parallel mode)
         ctx.pctx, ctx.eik_den = pctx, eik_den
-        ctx.n_aux = aux_x.shape[0] if fused else 0
-        gradients_o = go_all[:P_].view(N, S, 3).clone()           # own storage: the 8 GB workspace must not outlive backward
-        aux_sdf = sdf_all[P_:].clone() if fused else eng.zeros(0, 1)
-        aux_go = go_all[P_:].clone() if fused else eng.zeros(0, 3)
-        den_out = eik_den.clone()
+        ctx.n_aux = n_aux
         ctx.mark_non_differentiable(out["wmax_idx"], den_out)
-        return out["color"], out["depth"], gradients_o, eik, out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf, aux_go, den_out
+        return (out["color"], out["depth"], out["go"], eik.reshape(()), out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf,
+                aux_go, den_out)
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go, _g_den=None):
@@ -522,12 +530,11 @@ class _RenderFn(torch.autograd.Function):
             else:
                 r_, z_, pctx = rays, zs, ctx.pctx
             a = eng.composite_args(r_, z_, pctx.view("sdf").view(-1), pctx.view("go"), pctx.view("rgb"), var1, sample_dist, cos_anneal)
+            # (the auxiliary points' adjoint rows are appended by the compositing launch itself: no concatenation)
             bw = eng.composite_backward(a, g_color[i:j], g_depth[i:j], g_eik, ctx.eik_den, g_weights=sl(g_weights, i, j), g_cdf=sl(g_cdf, i, j),
-                                        g_wmax=sl(g_wmax, i, j), g_gradients_o=sl(g_go, i, j), d_invs_acc=d_invs_acc)
+                                        g_wmax=sl(g_wmax, i, j), g_gradients_o=sl(g_go, i, j), d_invs_acc=d_invs_acc, n_aux=ctx.n_aux,
+                                        g_aux_sdf=opt(g_aux_sdf), g_aux_go=opt(g_aux_go))
             d_sdf, d_go = bw["d_sdf"].view(-1, 1), bw["d_go"]
-            if ctx.n_aux:
-                d_sdf = torch.cat([d_sdf, z(g_aux_sdf, ctx.n_aux, 1)], 0)
-                d_go = torch.cat([d_go, z(g_aux_go, ctx.n_aux, 3)], 0)
             dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"], dweff=dweff)
             del pctx
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852): d var = d inv_s * 10 exp(10 var) inside the clip range

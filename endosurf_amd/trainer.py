@@ -38,6 +38,16 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     rays = renderer._rays32(batch["rays"])
     color_gt, depth_gt, mask_gt, cmask = batch["color"], batch["depth"], batch["mask"], batch["color_mask"]
     N = rays.shape[0]
+    eng = renderer.engine
+    need_p, need_n = renderer.perturb and u_perturb is None, u_neigh is None
+    if need_p or need_n:
+        # the step's random draws (stratified jitter [N], neighbour offsets [N,3]) in ONE library launch instead of two torch.rand's;
+        # in a captured step the device-resident step counter selects the subsequence (Trainer.train_step_graph)
+        u4 = eng.uniform(4 * N, getattr(renderer, "_rng_step_dev", None))
+        if need_p:
+            u_perturb = u4[:N]
+        if need_n:
+            u_neigh = u4[N:].view(N, 3)
     renderer._weights()          # weight-norm + packing once per step, with the autograd node (ray marching below is no_grad)
     # The 128-proposal ray-marching query fills the GPU; the 8 secant iterations after it and the hierarchical sampling
     # (coarse query + 3 dependent 8-sample queries) are independent chains of small, latency-bound launches: run the sampling
@@ -126,8 +136,11 @@ class _LossFn(torch.autograd.Function):
         f = lambda t: t.detach().to(torch.float32).contiguous()
         ins = [f(color_map), f(depth_map), f(eik).reshape(1), f(aux_sdf), f(aux_go), f(rays), f(eod_pts), f(color_gt), f(depth_gt), f(mask),
                f(cmask), (valid_sn.view(torch.uint8) if valid_sn.dtype == torch.bool else valid_sn.to(torch.uint8)).contiguous()]
-        terms = eng.empty(8)
-        grads = [eng.empty(N, 3), eng.empty(N, 1), eng.empty(1), eng.empty(3 * N, 1), eng.empty(3 * N, 3)]
+        terms, total = eng.empty(8), eng.empty(1)
+        # the five adjoints in ONE buffer (a non-unit seed of the backward pass scales them with one launch)
+        gbuf = eng.empty(16 * N + 1)
+        grads = [gbuf[0:3 * N].view(N, 3), gbuf[3 * N:4 * N].view(N, 1), gbuf[4 * N:4 * N + 1], gbuf[4 * N + 1:7 * N + 1].view(3 * N, 1),
+                 gbuf[7 * N + 1:16 * N + 1].view(3 * N, 3)]
         a = _lib.es_loss_args()
         for name, t in zip(("color_map", "depth_map", "eik", "aux_sdf", "aux_go", "rays", "eod_pts", "color_gt", "depth_gt", "mask", "cmask",
                             "valid_sn"), ins):
@@ -138,18 +151,28 @@ class _LossFn(torch.autograd.Function):
             setattr(a, name, _lib.ptr(t))
         if exact is not None:            # (global normalisers [4+], world): see compute_loss_fused
             a.den_global, a.world = _lib.ptr(exact[0]), float(exact[1])
+        a.total_out = _lib.ptr(total)
         _lib.check(eng.lib.es_train_loss(C.byref(a), eng.st()), "es_train_loss")
         ctx.set_materialize_grads(False)
-        ctx.grads = grads
+        ctx.grads, ctx.gbuf, ctx.eng, ctx.n = grads, gbuf, eng, N
         ctx.eik_shape = eik.shape
         ctx.mark_non_differentiable(terms)
-        return terms[6].clone(), terms
+        return total.reshape(()), terms
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         if g_total is None:
             return (None,) * 15
-        gc, gd, ge, gs, gg = torch._foreach_mul(ctx.grads, g_total)       # one multi-tensor launch
+        eng, N = ctx.eng, ctx.n
+        if g_total.data_ptr() == eng.ones1.data_ptr():       # the step's own seed (Trainer: loss.backward(gradient=engine.ones1)): d total = 1
+            gc, gd, ge, gs, gg = ctx.grads
+        else:
+            from . import _lib
+            out = eng.empty(16 * N + 1)
+            gt = g_total.detach().to(torch.float32).reshape(1)
+            _lib.check(eng.lib.es_scale(_lib.ptr(out), _lib.ptr(ctx.gbuf), 16 * N + 1, _lib.ptr(gt), eng.st()), "es_scale")
+            gc, gd, ge, gs, gg = (out[0:3 * N].view(N, 3), out[3 * N:4 * N].view(N, 1), out[4 * N:4 * N + 1], out[4 * N + 1:7 * N + 1].view(3 * N, 1),
+                                  out[7 * N + 1:16 * N + 1].view(3 * N, 3))
         return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None, None)
 
 
@@ -456,11 +479,8 @@ class Trainer:
 
         def body():
             schedule()
-            opt.zero_grad(set_to_none=True)
             # (optional "u_perturb" / "u_neigh" entries of the batch replace the random draws: reproducible tests)
-            loss, _, _ = self.loss_fn(r, g["batch"], global_step, self.loss_weights, self.surf_neig_rad, g["batch"].get("u_perturb"),
-                                      g["batch"].get("u_neigh"))
-            loss.backward()
+            loss, _, _ = self._step_body(g["batch"], global_step, g["batch"].get("u_perturb"), g["batch"].get("u_neigh"))
             if self.data_parallel:
                 return loss.detach(), opt.flat_grad(include_variance=True)
             opt.step()
@@ -475,6 +495,7 @@ class Trainer:
         # The device-resident scalars are visible to the launches of THIS call only: an eager train_step / render / checkpoint afterwards
         # must see the host schedule again (pg["lr"], grad_scale, get_cos_anneal_ratio(iter_step)), not the last graph step's values.
         opt.scalars_dev, r._cos_anneal_dev = g["scal"], g["scal"][3:]
+        r._rng_step_dev = g["state"]          # (the step counter selects the random subsequence of a replay: engine.uniform)
         try:
             if g["graph"] is None and g["eager"] < 2:        # lazy initialisation outside a capture: two ordinary steps
                 g["eager"] += 1
@@ -495,14 +516,26 @@ class Trainer:
                 opt.step_count = t
         finally:
             opt.scalars_dev, r._cos_anneal_dev = None, None
+            r._rng_step_dev = None
         r.model._epoch += 1                                # parameters changed behind Python's back: packed weights are stale
         r.model._pack_cache = None
         return g["loss"]
 
-    def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+    def _step_body(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        """zero_grad -> loss -> backward inside the engine's step arena (one memset for all of the step's zero-initialised buffers) and
+        with the engine's persistent ones as the backward seed (no fill launch; the loss node hands its adjoints on unscaled)."""
+        eng = self.renderer.engine
         self.optimizer.zero_grad(set_to_none=True)
-        loss, terms, ret = self.loss_fn(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
-        loss.backward()
+        eng.arena_begin(extra_floats=batch["rays"].shape[0] * 128)
+        try:
+            loss, terms, ret = self.loss_fn(self.renderer, batch, global_step, self.loss_weights, self.surf_neig_rad, u_perturb, u_neigh)
+            loss.backward(gradient=eng.ones1.reshape(loss.shape) if loss.numel() == 1 and loss.dtype == torch.float32 else None)
+        finally:
+            eng.arena_end()
+        return loss, terms, ret
+
+    def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        loss, terms, ret = self._step_body(batch, global_step, u_perturb, u_neigh)
         if isinstance(self.optimizer, FlatAdam):
             if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update
                 from .parallel import allreduce_flat

@@ -52,15 +52,12 @@ def _close(a, b, q_tol, q=0.999, frac_bad=2e-3):
     assert float((d > 1e-3 * scale).double().mean()) <= frac_bad, float((d > 1e-3 * scale).double().mean())
 
 
-@pytest.mark.parametrize("sdf_x3", [False, True])
 @pytest.mark.parametrize("mode", ["init", "trained"])
 @pytest.mark.parametrize("M,color", [(777, True), (4096, False), (20000, True)])
-def test_forward_with_saves_matches_fp32_buffers(mode, M, color, sdf_x3):
-    """``sdf_x3``: the SDF network's training kernels of the split-precision family too (engine.x3_sdf_chain; row-major SDF stacks)
-    instead of the fp32 SDF kernels between the family's deformation and colour kernels (the default)."""
+def test_forward_with_saves_matches_fp32_buffers(mode, M, color):
+    """The family's deformation and colour kernels around the fp32 SDF kernels (the SDF network stays fp32 in the training chain)."""
     from endosurf_amd import _lib
     eng, flat, weff, packed, net = _setup(31, mode, True)
-    eng.x3_sdf_chain = sdf_x3
     x, t, d, _ = _points(M, M)
     flags = _lib.PF_DEFORM | (_lib.PF_COLOR if color else 0) | _lib.PF_SAVE
     eng.x3_infer_min = 1
@@ -84,7 +81,7 @@ def test_forward_with_saves_matches_fp32_buffers(mode, M, color, sdf_x3):
     for name in ("S_S0", "S_ADJEPS"):
         _close(_buf(ctx, name, Mp, 64)[:, :M, :39], _buf(ref, name, Mp, 64)[:, :M, :39], 2e-5)
     for name in ("S_ACT", "S_RHO"):
-        _close(_stack(ctx, name, not sdf_x3)[:, :M], _stack(ref, name, True)[:, :M], 2e-5)
+        _close(_stack(ctx, name, True)[:, :M], _stack(ref, name, True)[:, :M], 2e-5)
     if color:
         assert qd(ctx.view("feat"), ref.view("feat")) < 5e-5
         assert qd(ctx.view("rgb"), ref.view("rgb"), 0.98) < 5e-5
@@ -92,14 +89,12 @@ def test_forward_with_saves_matches_fp32_buffers(mode, M, color, sdf_x3):
         _close(_buf(ctx, "C_H", Mp, 256, 8)[:, :M], _buf(ref, "C_H", Mp, 256, 8)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
 
 
-@pytest.mark.parametrize("sdf_x3", [False, True])
 @pytest.mark.parametrize("mode,color", [("init", True), ("trained", True), ("trained", False)])
-def test_backward_matches_fp32_chain_and_saved_adjoints(mode, color, sdf_x3):
+def test_backward_matches_fp32_chain_and_saved_adjoints(mode, color):
     """Same points, same output adjoints: the saved backward stacks and the gradient w.r.t. the effective weights of the two families."""
     from endosurf_amd import _lib
     M = 5000
     eng, flat, weff, packed, net = _setup(33, mode, True)
-    eng.x3_sdf_chain = sdf_x3
     eng.deterministic = True
     x, t, d, rng = _points(M, 5)
     g = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32)).cuda()
@@ -126,7 +121,7 @@ def test_backward_matches_fp32_chain_and_saved_adjoints(mode, color, sdf_x3):
     _close(a8, b8, 2e-5, q=0.99, frac_bad=2e-2)          # the J d rows are seeded by the colour network (d_c flips)
     _close(_buf(ctx, "S_TAU0", Mp, 64)[:, :M, :39], _buf(ref, "S_TAU0", Mp, 64)[:, :M, :39], 2e-5, q=0.99, frac_bad=2e-2)
     for name in ("S_TAU", "S_ZB"):
-        _close(_stack(ctx, name, not sdf_x3)[:, :M], _stack(ref, name, True)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
+        _close(_stack(ctx, name, True)[:, :M], _stack(ref, name, True)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
     _close(_buf(ctx, "XCBAR", Mp, 3)[:, :M], _buf(ref, "XCBAR", Mp, 3)[:, :M], 2e-5, q=0.99, frac_bad=2e-2)
     if color:
         for name, width, layers in (("C_Y", 256, 8), ("C_Y8", 4, 1), ("FEATBAR", 256, 1), ("XCBAR_C", 3, 1), ("GCBAR_C", 3, 1), ("VBAR_C", 3, 1)):
@@ -146,9 +141,8 @@ def test_backward_matches_fp32_chain_and_saved_adjoints(mode, color, sdf_x3):
             assert float((a - b).norm()) <= 1e-2 * float(b.norm()), (net_id, l, float((a - b).norm()), float(b.norm()))
 
 
-@pytest.mark.parametrize("sdf_x3", [False, True])
 @pytest.mark.parametrize("mode,use_deform,color", [("init", True, True), ("trained", True, True), ("trained", True, False), ("trained", False, True)])
-def test_point_backward_on_the_split_chain_vs_fp64_oracle(mode, use_deform, color, sdf_x3, monkeypatch):
+def test_point_backward_on_the_split_chain_vs_fp64_oracle(mode, use_deform, color, monkeypatch):
     """tests/test_gpu_backward.py::test_point_backward (autograd on the fp64 oracle, same budgets) with every chain kernel of the
     split-precision family: the threshold below which small evaluations stay on the fp32 kernels is lowered to 1 point."""
     from endosurf_amd.engine import Engine
@@ -157,20 +151,19 @@ def test_point_backward_on_the_split_chain_vs_fp64_oracle(mode, use_deform, colo
 
     def init(self, device):
         orig(self, device)
-        self.x3_infer_min, self.x3_sdf_chain = 1, sdf_x3
+        self.x3_infer_min = 1
     monkeypatch.setattr(Engine, "__init__", init)
     B.test_point_backward(mode, use_deform, color)
 
 
-@pytest.mark.parametrize("sdf_x3", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_training_loss_param_grads_on_the_split_chain(name, sdf_x3, monkeypatch):
+def test_training_loss_param_grads_on_the_split_chain(name, monkeypatch):
     from endosurf_amd.engine import Engine
     monkeypatch.setenv("ES_SPLIT_BF16", "1")
     orig = Engine.__init__
 
     def init(self, device):
         orig(self, device)
-        self.x3_infer_min, self.x3_sdf_chain = 1, sdf_x3
+        self.x3_infer_min = 1
     monkeypatch.setattr(Engine, "__init__", init)
     B.test_training_loss_param_grads(name)

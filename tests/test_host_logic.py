@@ -228,3 +228,11 @@ def test_workspace_budget_chunking_arithmetic():
     fake.__dict__.pop("_budget_points", None)
     with pytest.raises(_lib.EndoSurfHipError, match="workspace_gb"):
         f(1024, 64)
+
+
+def test_philox_reference_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 (kat_vectors): pins tests/philox_ref.py, the checker of es_uniform."""
+    from philox_ref import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

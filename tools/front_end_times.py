@@ -83,3 +83,61 @@ out["note"] = ("the render forward needs the sampling result; the concurrent fig
 print(json.dumps(out, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/front_end_times.json", "w"), indent=1)
+
+
+# ---- round 4: what would ONE grid per (sampling query i, secant iteration i) buy?  The launches of the merged schedule
+# are issued with the kernels that exist -- the 8 192 new sample points and the 1 024 secant points of an iteration as ONE 9 216-point
+# launch of the 16-point tiles (576 tiles; execution time does not depend on the data) -- in the order the merged step would issue them:
+#   [coarse query (side) || secant #1 (main)]  ->  3 x [up-sample; secant points; query(9 216); merge; secant update]  ->  up-sample
+#   ->  4 x [secant points; query(1 024); secant update]
+# and timed end to end like the concurrent schedule above.  Results are meaningless, the timing is that of the merged schedule.
+import ctypes as C
+from endosurf_amd import _lib
+eng = r.engine
+weff, packed = r._weights()
+weff = weff.detach()
+N, n0, S, n_imp = cfg["rays"], cfg["n_samples"], cfg["n_samples"] + cfg["n_importance"], cfg["n_importance"] // 4
+zc, zn = eng.empty(N, S), eng.empty(N, S)
+eng.ray_setup(rays, None, n0, 2.0 / n0, 0, zc)
+sdf_c = eng.query_sdf(eng.points(rays=rays, z=zc, n_per_ray=n0, ldz=S), weff, packed, True).view(N, n0)
+sdf_a, src, z_new = eng.empty(N, S), eng.empty(N, S, dtype=torch.int32), eng.empty(N, n_imp)
+xm, tm = (torch.rand(9216, 3, device=dev) - 0.5), torch.rand(9216, device=dev)
+x1, t1 = xm[:1024].contiguous(), tm[:1024].contiguous()
+xs, ts = eng.empty(N, 3), eng.empty(N)
+st = eng.st
+
+
+def secant_iter(x, t):
+    _lib.check(eng.lib.es_secant_points(_lib.ptr(rays), _lib.ptr(ms["d_pred"]), N, _lib.ptr(xs), _lib.ptr(ts), st()), "sp")
+    f = eng.query_sdf(eng.points(x=x, t=t), weff, packed, True)
+    _lib.check(eng.lib.es_secant_update(_lib.ptr(f), N, 0.0, _lib.ptr(ms["state"]), _lib.ptr(ms["d_pred"]), st()), "su")
+    return f
+
+
+def upsample(i):
+    _lib.check(eng.lib.es_upsample_step(_lib.ptr(rays), _lib.ptr(zc), S, _lib.ptr(sdf_c), n0, N, n0, n_imp, float(64 * 2 ** i), _lib.ptr(z_new),
+                                        _lib.ptr(zn), S, _lib.ptr(src), st()), "up")
+
+
+def merged():
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        eng.ray_setup(rays, None, n0, 2.0 / n0, 0, zc)
+        eng.query_sdf(eng.points(rays=rays, z=zc, n_per_ray=n0, ldz=S), weff, packed, True)
+    secant_iter(x1, t1)
+    main.wait_stream(side)
+    for i in range(3):
+        upsample(i)
+        f = secant_iter(xm, tm)                         # ONE 9 216-point launch: 8 192 sample points + 1 024 secant points
+        _lib.check(eng.lib.es_merge_sdf(_lib.ptr(sdf_c), n0, _lib.ptr(f), n_imp, _lib.ptr(src), S, N, n0, _lib.ptr(sdf_a), st()), "merge")
+    upsample(3)
+    for _ in range(4):
+        secant_iter(x1, t1)
+
+
+out["merged_grid_schedule_emulated_ms"] = timed(merged)
+out["query16_9216_points_ms"] = timed(lambda: eng.query_sdf(eng.points(x=xm, t=tm), weff, packed, True))
+out["query16_8192_points_ms"] = timed(lambda: eng.query_sdf(eng.points(x=xm[:8192].contiguous(), t=tm[:8192].contiguous()), weff, packed, True))
+out["query16_1024_points_ms"] = timed(lambda: eng.query_sdf(eng.points(x=x1, t=t1), weff, packed, True))
+print(json.dumps(out, indent=1))
+json.dump(out, open("gpurun_out/front_end_times.json", "w"), indent=1)

@@ -42,7 +42,6 @@ LOGICAL = {"k_point_fwd<0, 1>": "k_deform_fwd", "k_point_fwd<5, 1>": "k_deform_f
            "k_deform_vjp_x3r<false>": "k_deform_vjp_x3", "k_color_fwd_x3r<true, true>": "k_color_fwd_x3", "k_color_fwd_x3r<true, false>": "k_color_fwd_x3",
            "k_color_fwd_x3r<false, true>": "k_color_fwd_x3", "k_color_fwd_x3r<false, false>": "k_color_fwd_x3", "k_deform_tan_x3r": "k_deform_tan_x3",
            "k_deform_bwd_x3r": "k_deform_bwd_x3", "k_color_bwd_x3r<true>": "k_color_bwd_x3", "k_color_bwd_x3r<false>": "k_color_bwd_x3",
-           "k_sdf_tan_x3r": "k_sdf_bwd_x3", "k_sdf_rev_x3r<true>": "k_sdf_bwd_x3", "k_sdf_rev_x3r<false>": "k_sdf_bwd_x3",
            "k_wgrad_x3<0, false>": "k_wgrad_x3[deform]", "k_wgrad_x3<1, false>": "k_wgrad_x3[sdf]", "k_wgrad_x3<2, false>": "k_wgrad_x3[color]"}
 for _d in (True, False):
     for _c in (True, False):
