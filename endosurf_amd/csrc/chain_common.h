@@ -21,6 +21,13 @@ namespace es {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// max(z, 0) as ONE instruction: fmaxf() is two (the compiler canonicalises the MFMA result first: v_max z, z)
+__device__ __forceinline__ float relu1(float z) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(z));
+    return r;
+}
+
 constexpr int TM = 64;                     // rows per workgroup tile
 constexpr int NTHREADS = 256;              // 4 wavefronts
 constexpr int MAIN_FLOATS = HID * TM;      // 64 KiB main activation tile
@@ -164,6 +171,55 @@ __device__ __forceinline__ void for_quads_half(f32x16 (&acc)[2][2], int nt0, int
         }
 }
 
+// ---- epilogue without address arithmetic or a bias add -------------------------------------------------------------------------
+// Every non-MFMA instruction of a wave adds to its MFMA time on this part (measured: softplus on the raw exp / log units, -13 VALU
+// instructions per element, took 3 % off k_query_sdf), so the epilogue of the hot kernels carries none it can avoid:
+//  * the LDS address of a lane's quad (row tile ri, quad q) of n-tile ni is  o[ri*4 + q] + 2048 ni  floats: the XOR swizzle takes
+//    RTC*4 values per lane (they do not depend on the layer), the n-tile is an immediate offset -> RTC*4 pinned registers instead of
+//    ~7 VALU instructions per ds_write_b128;
+//  * the bias is the accumulator's INITIAL value (a lane's 16 registers of an accumulator block all belong to one column): the
+//    v_mov that zeroed the accumulator writes the bias instead, and the bias load is issued a layer ahead.
+template <int RTC> struct QuadOff { int o[RTC * 4]; };
+template <int RTC>
+__device__ __forceinline__ QuadOff<RTC> quad_offsets(int rt0, int nt0, int lane) {
+    QuadOff<RTC> qo;
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int v = swz(nt0 * 32 + lo, (rt0 + ri) * 32 + 8 * q + 4 * hi);
+            asm volatile("" : "+v"(v));          // opaque: keep the value in its register instead of re-deriving it at every store
+            qo.o[ri * 4 + q] = v;
+        }
+    return qo;
+}
+template <int RTC, int NTC>
+__device__ __forceinline__ void acc_fill(f32x16 (&acc)[RTC][NTC], const float (&b)[NTC]) {
+#pragma unroll
+    for (int i = 0; i < RTC; ++i)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b[j];
+}
+// f(row, col, v[4], off): off = LDS float offset of the quad (see QuadOff)
+template <int RTC, int NTC, class F>
+__device__ __forceinline__ void for_quads_off(f32x16 (&acc)[RTC][NTC], const QuadOff<RTC>& qo, int rt0, int nt0, int lane, F&& f) {
+    const int lo = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ri = 0; ri < RTC; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < NTC; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[ri][ni][4 * q + 0], acc[ri][ni][4 * q + 1], acc[ri][ni][4 * q + 2], acc[ri][ni][4 * q + 3]};
+                f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v, qo.o[ri * 4 + q] + 2048 * ni);
+            }
+}
+__device__ __forceinline__ void lds_store_quad_at(float* At, int off, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(At + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void lds_store_quad(float* At, int col, int row, const float (&v)[4]) {
     *reinterpret_cast<float4*>(&At[swz(col, row)]) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -274,7 +330,7 @@ __device__ __forceinline__ float softplus100(float z) {
     // raw v_exp_f32 / v_log_f32 (base 2): the logarithm's argument is in (1, 2], so the range handling __logf carries (compare, ldexp,
     // select, a 4-instruction correction: 13 of its 20 VALU instructions) has nothing to do; 64 elements per lane and layer
     const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(z));
-    return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.f + e), fmaxf(z, 0.f));
+    return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.f + e), relu1(z));
 }
 // softplus'(z) = sigmoid(100 z) recovered from s = softplus(z):  1 - exp(-100 s)   (series where that cancels)
 __device__ __forceinline__ float softplus100_grad_from_s(float s) {
