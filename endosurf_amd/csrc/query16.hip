@@ -26,29 +26,70 @@ __device__ __forceinline__ int swz16(int k, int r) { return k * T16 + (r ^ (((k 
 // the first three groups of the NEXT layer before this layer's epilogue and barriers (``Wnext``; the caller passes ``primed`` to the
 // next call).  With one group of distance every group waited ~100-400 cycles for L2 (57 stall cycles per 32-cycle MFMA).
 struct Ring16 { float4 b[4][4]; };
+// Where the weights of a segment come from: one 64-bit lane address per n-tile, centred on k-group 4 of an 8-group window, so that the
+// eight groups of a window are IMMEDIATE offsets (-4 .. +3 KiB) and a layer costs 4 address adds per window (8 per 256-wide layer).
+// Left to the compiler, every one of a layer's 64 loads got its own address from a scalar constant: 58 v_lshl_add_u64 + 50 v_readlane
+// (the constants did not fit the SGPR file) + 29 hazard nops per layer, on the critical path of a one-wave-per-SIMD kernel.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(1))) float4* gptr4;      // global address space survives the opaque register pin (else: flat loads)
+#else
+typedef const float4* gptr4;                                         // (host pass of the same source: the kernels are never instantiated there)
+#endif
+struct WStream16 { gptr4 p[4]; };
 template <int KG>
-__device__ __forceinline__ void ring16_load(Ring16& R, const float4* __restrict__ W, int nt0, int lane, int g) {
+__device__ __forceinline__ WStream16 wstream16(const float4* __restrict__ W, int nt0, int lane) {
+    WStream16 ws;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const float4* q = W + (size_t)((nt0 + ni) * KG + 4) * 64 + lane;
+        asm volatile("" : "+v"(q));          // opaque: the loads below must use THIS register pair + an immediate
+        ws.p[ni] = (gptr4)q;
+    }
+    return ws;
+}
+__device__ __forceinline__ void wstream16_next_window(WStream16& ws) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        gptr4 q = ws.p[ni] + 8 * 64;
+        asm volatile("" : "+v"(q));
+        ws.p[ni] = q;
+    }
+}
+// k-group g of the stream's segment into ring slot g & 3 (g is a compile-time constant at every call site)
+__device__ __forceinline__ void ring16_load(Ring16& R, const WStream16& ws, int g) {
     const int slot = g & 3;
 #ifdef ES_Q16_NO_W          // dev probe: every k-group of every layer reads the same (L1-resident) weights
-    g = 0;
+    const int gl = -4;
+#else
+    const int gl = (g & 7) - 4;
 #endif
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) R.b[slot][ni] = W[(size_t)((nt0 + ni) * KG + g) * 64 + lane];
+    for (int ni = 0; ni < 4; ++ni) R.b[slot][ni] = ws.p[ni][gl * 64];
 }
 template <int KG>
-__device__ __forceinline__ void ring16_prime(Ring16& R, const float4* __restrict__ W, int nt0, int lane) {
+__device__ __forceinline__ WStream16 ring16_prime(Ring16& R, const float4* __restrict__ W, int nt0, int lane) {
+    WStream16 ws = wstream16<KG>(W, nt0, lane);
 #pragma unroll
-    for (int g = 0; g < 3 && g < KG; ++g) ring16_load<KG>(R, W, nt0, lane, g);
+    for (int g = 0; g < 3 && g < KG; ++g) ring16_load(R, ws, g);
+    return ws;
 }
+// ``ws`` = the stream of W when the previous call primed the ring (``primed``); on return it is the stream of Wnext if one was given
 template <int KG, int KGN = 16>
-__device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const float4* __restrict__ W, int nt0, int lane, Ring16& R, bool primed = false,
-                                       const float4* __restrict__ Wnext = nullptr) {
+__device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const float4* __restrict__ W, int nt0, int lane, Ring16& R, WStream16& ws,
+                                       bool primed = false, const float4* __restrict__ Wnext = nullptr) {
+    static_assert(KG <= 8 || KG == 16, "window bookkeeping below: one or two 8-group windows");
     const int lo = lane & 15, hi = lane >> 4;
-    if (!primed) ring16_prime<KG>(R, W, nt0, lane);
+    if (!primed) ws = ring16_prime<KG>(R, W, nt0, lane);
+    WStream16 wn;
+    if (Wnext != nullptr) wn = wstream16<KGN>(Wnext, nt0, lane);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
-        if (g + 3 < KG) ring16_load<KG>(R, W, nt0, lane, g + 3);
-        else if (Wnext != nullptr) ring16_load<KGN>(R, Wnext, nt0, lane, g + 3 - KG);      // the ring slot (g + 3) & 3 is free: KG % 4 == 0 here
+        if (g + 3 < KG) {
+            if (g + 3 == 8) wstream16_next_window(ws);
+            ring16_load(R, ws, g + 3);
+        } else if (Wnext != nullptr) {
+            ring16_load(R, wn, g + 3 - KG);      // the ring slot (g + 3) & 3 is free: KG % 4 == 0 here
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = At[swz16(16 * g + 4 * j + hi, lo)];
@@ -56,6 +97,7 @@ __device__ __forceinline__ void gemm16(f32x4v (&acc)[4], const float* At, const 
             for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f4c(R.b[g & 3][ni], j), acc[ni], 0, 0, 0);
         }
     }
+    if (Wnext != nullptr) ws = wn;
 }
 
 // C/D layout of the 16x16 MFMA: col = lane&15, rows 4*(lane>>4) + reg: one quad of 4 consecutive rows per (lane, n-tile)
@@ -124,6 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
     const int row0 = blockIdx.x * T16;
     const int nt0 = 4 * wave;
     Ring16 ring;
+    WStream16 wst;
 
     if (tid < 16) {
         float x[3], t, d[3];
@@ -137,16 +180,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bq[ni] = bias[(nt0 + ni) * 16 + (lane & 15)];
     };
-    auto relu_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
+    auto relu_epi = [&](f32x4v(&acc)[4]) {
         epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
-            const float b = bq[ni];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
         });
     };
-    auto zero4 = [&](f32x4v(&acc)[4]) {
+    // the bias is the accumulators' initial value (a lane's four registers of an n-tile belong to one column): no add in the epilogue
+    auto fill4 = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{bq[ni], bq[ni], bq[ni], bq[ni]};
     };
     if (DEFORM) {
         encode3_16<6>(aux, 0, px, tid);
@@ -163,29 +206,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
         __syncthreads();
         {
             f32x4v acc[4];
-            zero4(acc);
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + 0]);
-            gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane, ring, false, packed + tb.p16off[1]);
-            relu_epi(acc, bq);
+            fill4(acc, bq);
+            gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane, ring, wst, false, packed + tb.p16off[1]);
+            relu_epi(acc);
         }
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             f32x4v acc[4];
-            zero4(acc);
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + l]);
-            gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane, ring, true, l < 7 ? packed + tb.p16off[l + 1] : nullptr);
+            fill4(acc, bq);
+            gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane, ring, wst, true, l < 7 ? packed + tb.p16off[l + 1] : nullptr);
             __syncthreads();
             epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
                 if (l == 3 && col >= 204) {                                  // IDR skip: [h(204) | enc(52)]
                     const float4 e = *reinterpret_cast<const float4*>(&aux[swz16(col - 204, rb)]);
                     v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
                 } else {
-                    const float b = bq[ni];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + b, 0.f);
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                 }
             });
             __syncthreads();
@@ -202,37 +244,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
     }
     encode3_16<6>(aux, 0, px, tid);
     __syncthreads();
-    auto sp_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
+    auto sp_epi = [&](f32x4v(&acc)[4]) {
         epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
-            const float b = bq[ni];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
         });
     };
     {
         f32x4v acc[4];
-        zero4(acc);
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + 0]);
-        gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane, ring);
-        ring16_prime<16>(ring, packed + tb.p16off[9], nt0, lane);
-        sp_epi(acc, bq);
+        fill4(acc, bq);
+        gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane, ring, wst);
+        wst = ring16_prime<16>(ring, packed + tb.p16off[9], nt0, lane);
+        sp_epi(acc);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x4v acc[4];
-        zero4(acc);
         const int pi = l <= 4 ? 8 + l : 8 + l + 1;          // P16_SEGS order: SF0..SF3, SF4M, SF4A, SF5..SF7
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + l]);
+        fill4(acc, bq);
         // the skip layer's extra columns use the ring in between: no priming across it
         const bool chain_next = l != 4 && l < 7;
         const int pn = l + 1 <= 4 ? 8 + l + 1 : 8 + l + 2;
-        gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane, ring, l != 5, chain_next ? packed + tb.p16off[pn] : nullptr);
-        if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane, ring);
+        gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane, ring, wst, l != 5, chain_next ? packed + tb.p16off[pn] : nullptr);
+        if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane, ring, wst);
         __syncthreads();
-        sp_epi(acc, bq);
+        sp_epi(acc);
         __syncthreads();
     }
     smalln16<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
@@ -246,8 +287,12 @@ int query_sdf16(const PointSrc& src, const float* packed, const float* weff, flo
     const dim3 grid((src.M + T16 - 1) / T16), block(NTHREADS);
     const float4* pk = reinterpret_cast<const float4*>(packed);
     ScopedTimer tm(KID_QUERY16, src.M, st);
-    if (use_deform) hipLaunchKernelGGL(k_query_sdf16<true>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
-    else hipLaunchKernelGGL(k_query_sdf16<false>, grid, block, Q16_LDS_BYTES, st, src, tb, pk, weff, sdf_out);
+    // the launch asks for 56 KiB of LDS (the carve uses 24): at most TWO workgroups per CU.  At 168 registers three would fit, and a CU
+    // that takes three 16-point tiles of an 8 192-point launch finishes half a tile time after the ones that took two
+    constexpr int LDS_REQ = 56 * 1024;
+    static_assert(LDS_REQ >= Q16_LDS_BYTES, "carve");
+    if (use_deform) hipLaunchKernelGGL(k_query_sdf16<true>, grid, block, LDS_REQ, st, src, tb, pk, weff, sdf_out);
+    else hipLaunchKernelGGL(k_query_sdf16<false>, grid, block, LDS_REQ, st, src, tb, pk, weff, sdf_out);
     return hip_last("query_sdf16");
 }
 
