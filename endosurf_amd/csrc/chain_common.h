@@ -171,14 +171,24 @@ __device__ __forceinline__ void for_quads_half(f32x16 (&acc)[2][2], int nt0, int
         }
 }
 
+// v[0..3] += b as two packed adds (v_pk_add_f32): the same roundings as four scalar adds
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void add_bias4(float (&v)[4], float b) {
+    const f32x2v bb = {b, b};
+    f32x2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    lo += bb; hi += bb;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+}
 // ---- epilogue without address arithmetic or a bias add -------------------------------------------------------------------------
 // Every non-MFMA instruction of a wave adds to its MFMA time on this part (measured: softplus on the raw exp / log units, -13 VALU
 // instructions per element, took 3 % off k_query_sdf), so the epilogue of the hot kernels carries none it can avoid:
 //  * the LDS address of a lane's quad (row tile ri, quad q) of n-tile ni is  o[ri*4 + q] + 2048 ni  floats: the XOR swizzle takes
 //    RTC*4 values per lane (they do not depend on the layer), the n-tile is an immediate offset -> RTC*4 pinned registers instead of
 //    ~7 VALU instructions per ds_write_b128;
-//  * the bias is the accumulator's INITIAL value (a lane's 16 registers of an accumulator block all belong to one column): the
-//    v_mov that zeroed the accumulator writes the bias instead, and the bias load is issued a layer ahead.
+//  * the bias is requested a layer ahead and added as packed pairs (add_bias4).  (As the accumulators' INITIAL value it would cost
+//    nothing at all -- the chain kernels with continuous outputs may do that -- but the no-grad queries feed DISCRETE decisions, the first
+//    sign change of ray marching: a different rounding order moves a proposal that sits within 1e-7 of the surface to its other side,
+//    and the golden surface-neighbour case (tests/test_gpu_render.py::test_aux_forward) holds such a ray.)
 template <int RTC> struct QuadOff { int o[RTC * 4]; };
 template <int RTC>
 __device__ __forceinline__ QuadOff<RTC> quad_offsets(int rt0, int nt0, int lane) {
@@ -203,7 +213,7 @@ __device__ __forceinline__ void acc_fill(f32x16 (&acc)[RTC][NTC], const float (&
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = b[j];
 }
-// f(row, col, v[4], off): off = LDS float offset of the quad (see QuadOff)
+// f(row, col, v[4], off, ni): off = LDS float offset of the quad (see QuadOff), ni = n-tile index within the wave tile
 template <int RTC, int NTC, class F>
 __device__ __forceinline__ void for_quads_off(f32x16 (&acc)[RTC][NTC], const QuadOff<RTC>& qo, int rt0, int nt0, int lane, F&& f) {
     const int lo = lane & 31, hi = lane >> 5;
@@ -214,7 +224,7 @@ __device__ __forceinline__ void for_quads_off(f32x16 (&acc)[RTC][NTC], const Qua
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4] = {acc[ri][ni][4 * q + 0], acc[ri][ni][4 * q + 1], acc[ri][ni][4 * q + 2], acc[ri][ni][4 * q + 3]};
-                f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v, qo.o[ri * 4 + q] + 2048 * ni);
+                f((rt0 + ri) * 32 + 8 * q + 4 * hi, (nt0 + ni) * 32 + lo, v, qo.o[ri * 4 + q] + 2048 * ni, ni);
             }
 }
 __device__ __forceinline__ void lds_store_quad_at(float* At, int off, const float (&v)[4]) {

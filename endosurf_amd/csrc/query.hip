@@ -64,14 +64,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
         zero_rows(aux, 52, 56, tid);
         __syncthreads();
         Q_STAMP(1);
-        float bn[2];          // the NEXT layer's bias of this lane's two columns: requested a layer ahead, it is the accumulators' initial value
+        float bc[2], bn[2];   // this layer's and the NEXT layer's bias of this lane's two columns (requested a layer ahead)
         bias2(bn, weff + tb.boff[NET_D * LAYERS + 0]);
         {
             f32x16 acc[RTC][2];
-            acc_fill(acc, bn);
+            acc_zero(acc);
+            bc[0] = bn[0]; bc[1] = bn[1];
             bias2(bn, weff + tb.boff[NET_D * LAYERS + 1]);
             gemm_seg<7, RTC, 2>(acc, aux, packed + tb.segoff[DF0], 0, 2 * wave, lane);
-            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off) {
+            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                add_bias4(v, bc[ni]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                 lds_store_quad_at(mainT, off, v);
@@ -82,24 +84,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             f32x16 acc[RTC][2];
-            acc_fill(acc, bn);
+            acc_zero(acc);
+            bc[0] = bn[0]; bc[1] = bn[1];
             if (l < 7) bias2(bn, weff + tb.boff[NET_D * LAYERS + l + 1]);
             Q_STAMP(10 + l);
             gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[DF0 + l], 0, 2 * wave, lane);
             Q_STAMP(20 + l);
             __syncthreads();
             if (l == 3 && wave == 3) {      // (wave-uniform: the skip's address arithmetic stays out of every other epilogue)
-                for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off) {
+                for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
                     if (col >= 204) {
                         lds_load_quad(aux, col - 204, row, v);   // IDR skip: next input = [h(204) | enc(52)] (1/sqrt2 folded into W4)
                     } else {
+                        add_bias4(v, bc[ni]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                     }
                     lds_store_quad_at(mainT, off, v);
                 });
             } else {
-                for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off) {
+                for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                    add_bias4(v, bc[ni]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                     lds_store_quad_at(mainT, off, v);
@@ -122,14 +127,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     encode3<6>(aux, 0, px, tid);
     zero_rows(aux, 39, 40, tid);
     __syncthreads();
-    float bn[2];
+    float bc[2], bn[2];
     bias2(bn, weff + tb.boff[NET_S * LAYERS + 0]);
     {
         f32x16 acc[RTC][2];
-        acc_fill(acc, bn);
+        acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
         bias2(bn, weff + tb.boff[NET_S * LAYERS + 1]);
         gemm_seg<5, RTC, 2>(acc, aux, packed + tb.segoff[SF0], 0, 2 * wave, lane);
-        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off) {
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            add_bias4(v, bc[ni]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
             lds_store_quad_at(mainT, off, v);
@@ -140,14 +147,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x16 acc[RTC][2];
-        acc_fill(acc, bn);
+        acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
         if (l < 7) bias2(bn, weff + tb.boff[NET_S * LAYERS + l + 1]);
         Q_STAMP(30 + l);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
         gemm_seg<32, RTC, 2>(acc, mainT, packed + tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, RTC, 2>(acc, aux, packed + tb.segoff[SF4A], 0, 2 * wave, lane);   // NeRF skip: + enc part
         __syncthreads();
-        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off) {
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            add_bias4(v, bc[ni]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
             lds_store_quad_at(mainT, off, v);

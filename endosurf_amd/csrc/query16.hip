@@ -180,16 +180,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bq[ni] = bias[(nt0 + ni) * 16 + (lane & 15)];
     };
-    auto relu_epi = [&](f32x4v(&acc)[4]) {
+    auto relu_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
         epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
+            add_bias4(v, bq[ni]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
         });
     };
-    // the bias is the accumulators' initial value (a lane's four registers of an n-tile belong to one column): no add in the epilogue
-    auto fill4 = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
+    auto zero4 = [&](f32x4v(&acc)[4]) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{bq[ni], bq[ni], bq[ni], bq[ni]};
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
     };
     if (DEFORM) {
         encode3_16<6>(aux, 0, px, tid);
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
             f32x4v acc[4];
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + 0]);
-            fill4(acc, bq);
+            zero4(acc);
             gemm16<4>(acc, aux, packed + tb.p16off[0], nt0, lane, ring, wst, false, packed + tb.p16off[1]);
-            relu_epi(acc);
+            relu_epi(acc, bq);
         }
         __syncthreads();
 #pragma unroll 1
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
             f32x4v acc[4];
             float bq[4];
             load_bias(bq, weff + tb.boff[NET_D * LAYERS + l]);
-            fill4(acc, bq);
+            zero4(acc);
             gemm16<16>(acc, mainT, packed + tb.p16off[l], nt0, lane, ring, wst, true, l < 7 ? packed + tb.p16off[l + 1] : nullptr);
             __syncthreads();
             epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
                     const float4 e = *reinterpret_cast<const float4*>(&aux[swz16(col - 204, rb)]);
                     v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
                 } else {
+                    add_bias4(v, bq[ni]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                 }
@@ -244,8 +245,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
     }
     encode3_16<6>(aux, 0, px, tid);
     __syncthreads();
-    auto sp_epi = [&](f32x4v(&acc)[4]) {
+    auto sp_epi = [&](f32x4v(&acc)[4], const float(&bq)[4]) {
         epi16(acc, mainT, nt0, lane, [&](int col, int rb, float(&v)[4], int ni) {
+            add_bias4(v, bq[ni]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
         });
@@ -254,10 +256,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
         f32x4v acc[4];
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + 0]);
-        fill4(acc, bq);
+        zero4(acc);
         gemm16<3>(acc, aux, packed + tb.p16off[8], nt0, lane, ring, wst);
         wst = ring16_prime<16>(ring, packed + tb.p16off[9], nt0, lane);
-        sp_epi(acc);
+        sp_epi(acc, bq);
     }
     __syncthreads();
 #pragma unroll 1
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf16(PointSrc src, Tabs 
         const int pi = l <= 4 ? 8 + l : 8 + l + 1;          // P16_SEGS order: SF0..SF3, SF4M, SF4A, SF5..SF7
         float bq[4];
         load_bias(bq, weff + tb.boff[NET_S * LAYERS + l]);
-        fill4(acc, bq);
+        zero4(acc);
         // the skip layer's extra columns use the ring in between: no priming across it
         const bool chain_next = l != 4 && l < 7;
         const int pn = l + 1 <= 4 ? 8 + l + 1 : 8 + l + 2;
         gemm16<16>(acc, mainT, packed + tb.p16off[pi], nt0, lane, ring, wst, l != 5, chain_next ? packed + tb.p16off[pn] : nullptr);
         if (l == 4) gemm16<3>(acc, aux, packed + tb.p16off[13], nt0, lane, ring, wst);
         __syncthreads();
-        sp_epi(acc);
+        sp_epi(acc, bq);
         __syncthreads();
     }
     smalln16<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);

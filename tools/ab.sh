@@ -8,6 +8,6 @@ for r in $(seq $R); do
     cp $L/variant_$v.so $L/libendosurf_hip.so
     python bench.py --no-cpu-baseline --headline-only --steps 30 --warmup 5 "$@" 2>/dev/null | python -c "
 import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(b['ms_per_step'],3), round(b['value']), {s['kernel']:s['ms_per_step'] for s in b['kernel_symbols'] if 'wgrad' in s['kernel'] or 'query' in s['kernel']})"
+b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(b['ms_per_step'],3), round(b['value']), {s['kernel']:s['ms_per_step'] for s in b['kernel_symbols'] if True})"
   done
 done
