@@ -2,6 +2,7 @@
 // + reverse sweep, colour.  A header so that the split-precision family's launches can host the fp32 bodies of a batch's colour-less
 // tail (infer_x3r.hip / train_x3r.hip: two-segment launches across the families).
 #pragma once
+#include <type_traits>
 #include "chain_common.h"
 #include "encode.h"
 #include "tabs.h"
@@ -86,39 +87,58 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     float* U = wsb(a, WS_D_U);
     unsigned* MK = reinterpret_cast<unsigned*>(wsb(a, WS_D_MASK));
     const size_t nt32 = (size_t)a.L.Mp / 32;
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l];
+    // Epilogue.  Every non-MFMA instruction of a wave adds to its MFMA time, so the regular layers carry no per-lane
+    // branch: the skip layer's copy (l == 3, columns >= 204: wave 3 only) is its own instantiation behind a wave-uniform test -- inside
+    // one lambda it cost every quad of every layer an exec-mask branch and the phi moves behind it (708 -> ~300 instructions per layer
+    // and wave) --, the bias is requested a layer ahead (two registers) and ``save`` is uniform.
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    auto bias2 = [&](float(&b)[2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l] + 64 * wave + (lane & 31);
+        b[0] = bias[0]; b[1] = bias[32];
+    };
+    auto epi_impl = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2], auto SKIP, auto SAVE) {
         float* Ul = U + (size_t)l * rows2 * 256;
         unsigned bits = 0;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {       // rows: value, tangent, value, tangent
-            if (l == 3 && col >= 204) {
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {       // rows: value, tangent, value, tangent
+            const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+            if (decltype(SKIP)::value && col >= 204) {
                 lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
             } else {
-                const float b = bias[col];
-                const float a0 = v[0] + b, a2 = v[2] + b;
+                const float a0 = v[0] + bc[ni], a2 = v[2] + bc[ni];
                 const bool m0 = a0 > 0.f, m2 = a2 > 0.f;         // the ReLU mask of a value row gates its tangent
                 v[0] = m0 ? a0 : 0.f; v[1] = m0 ? v[1] : 0.f; v[2] = m2 ? a2 : 0.f; v[3] = m2 ? v[3] : 0.f;
                 bits |= (m0 ? 1u : 0u) << (2 * qi) | (m2 ? 1u : 0u) << (2 * qi + 1);
             }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Ul, grow0, 256, row, col, v);
+            lds_store_quad_at(mainT, off, v);
+            if (decltype(SAVE)::value) g_store_quad(Ul, grow0, 256, row, col, v);
         });
         MK[((size_t)l * nt32 + tile) * 256 + tid] = bits;        // the masks of the VJP / tangent / reverse sweeps
     };
+    auto epi = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2], auto SKIP) {
+        if (save) epi_impl(acc, l, bc, SKIP, std::true_type{});
+        else epi_impl(acc, l, bc, SKIP, std::false_type{});
+    };
+    float bc[2], bn[2];
+    bias2(bn, 0);
     {
         f32x16 acc[2][2];
         acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        bias2(bn, 1);
         gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
-        epi(acc, 0);
+        epi(acc, 0, bc, std::false_type{});
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x16 acc[2][2];
         acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        if (l < 7) bias2(bn, l + 1);
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l);
+        if (l == 3 && wave == 3) epi(acc, l, bc, std::true_type{});
+        else epi(acc, l, bc, std::false_type{});
         __syncthreads();
     }
     smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_D * LAYERS + 8], 256, red, tid);
@@ -154,6 +174,7 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     const int hi = lane >> 5;
     float* R = wsb(a, WS_D_R);
 
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
     if (tid < 64) {
         const float* gc = wsb(a, WS_GC) + (grow0 + tid) * 3;
         g8[tid] = gc[0]; g8[64 + tid] = gc[1]; g8[128 + tid] = gc[2];
@@ -183,18 +204,24 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
         else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
         __syncthreads();
         float* Rl = R + (size_t)(l - 1) * Mp * 256;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            if (l == 4 && col >= 204) {
-                lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
+        // (the skip layer's per-lane test and ``save`` are compile-time in the epilogue: see deform_fwd_tile)
+        auto epi = [&](auto SKIP, auto SAVE) {
+            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+                if (decltype(SKIP)::value && col >= 204) {
+                    lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
-            } else {
+                    for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
-            }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Rl, grow0, 256, row, col, v);
-        });
+                    for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
+                }
+                lds_store_quad_at(mainT, off, v);
+                if (decltype(SAVE)::value) g_store_quad(Rl, grow0, 256, row, col, v);
+            });
+        };
+        if (l == 4 && wave == 3) { if (save) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
+        else { if (save) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
         __syncthreads();
     }
     {   // adjoint of the encoding input: += W_0^T r_0
@@ -259,33 +286,44 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         for (int k = c4; k < 40; k += 4) S0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
     float* SACT = wsb(a, WS_S_ACT);
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + l];
+    // (bias requested a layer ahead: inside the epilogue the 16 quads reloaded it after every store -- 16 loads, their waits and nops)
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    auto bias2 = [&](float(&b)[2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + l] + 64 * wave + (lane & 31);
+        b[0] = bias[0]; b[1] = bias[32];
+    };
+    auto epi = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2]) {
         float* Sl = SACT + (size_t)l * Mp * 256;
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
-            const float b = bias[col];
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            add_bias4(v, bc[ni]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i] + b);
-            lds_store_quad(mainT, col, row, v);
+            for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
+            lds_store_quad_at(mainT, off, v);
             g_store_quad_f(Sl, grow0, row, col, v);
         });
     };
+    float bc[2], bn[2];
+    bias2(bn, 0);
     {
         f32x16 acc[2][2];
         acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        bias2(bn, 1);
         gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
-        epi(acc, 0);
+        epi(acc, 0, bc);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x16 acc[2][2];
         acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        if (l < 7) bias2(bn, l + 1);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
         if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, l);
+        epi(acc, l, bc);
         __syncthreads();
     }
     // last layer: 256 geometry features (MFMA) + sdf (row 0, VALU)
@@ -310,15 +348,18 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
     float* RHO = wsb(a, WS_S_RHO);
     {   // rho_7 = softplus'(z_7) * W8[0,:]   (mainT still holds s_8 = softplus(z_7))
         const float* w8 = a.weff + a.tb.woff[NET_S * LAYERS + 8];
-        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
-            float v[4];
-            lds_load_quad(mainT, col, row, v);
-            const float w = w8[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(v[i]) * w;
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad_f(RHO + (size_t)7 * Mp * 256, grow0, row, col, v);
-        });
+        const float w8c[2] = {w8[64 * wave + (lane & 31)], w8[64 * wave + 32 + (lane & 31)]};
+        auto rho7 = [&](auto SAVE) {
+            f32x16 dummy[2][2];
+            for_quads_off(dummy, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                const float4 t = *reinterpret_cast<const float4*>(mainT + off);
+                v[0] = softplus100_grad_from_s(t.x) * w8c[ni]; v[1] = softplus100_grad_from_s(t.y) * w8c[ni];
+                v[2] = softplus100_grad_from_s(t.z) * w8c[ni]; v[3] = softplus100_grad_from_s(t.w) * w8c[ni];
+                lds_store_quad_at(mainT, off, v);
+                if (decltype(SAVE)::value) g_store_quad_f(RHO + (size_t)7 * Mp * 256, grow0, row, col, v);
+            });
+        };
+        if (save) rho7(std::true_type{}); else rho7(std::false_type{});
     }
     __syncthreads();
 #pragma unroll 1
@@ -336,12 +377,16 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         float S[16][4];                                          // all 16 quads requested at once: one memory round trip
         prefetch_quads_f<2, 2>(S, Sl, grow0, 0, 2 * wave, lane);
         __syncthreads();
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+        auto repi = [&](auto SAVE) {
+            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad_f(RHO + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
-        });
+                for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
+                lds_store_quad_at(mainT, off, v);
+                if (decltype(SAVE)::value) g_store_quad_f(RHO + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
+            });
+        };
+        if (save) repi(std::true_type{}); else repi(std::false_type{});
         if (l == 4)
             for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
         __syncthreads();
@@ -433,23 +478,38 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
         for (int k = c4; k < 96; k += 4) CIN[(grow0 + r) * 128 + k] = mainT[swz(k, r)];
     }
     float* CH = wsb(a, WS_C_H);
-    auto epi = [&](f32x16(&acc)[2][2], int l) {
-        const float* bias = a.weff + a.tb.boff[NET_C * LAYERS + l];
+    // lean epilogue (see deform_fwd_tile): bias requested a layer ahead, ``save`` compile-time, pinned LDS offsets, the mask bits of a
+    // quad gathered in 32-bit halves (quads 0..7 | 8..15) instead of 64-bit shifts
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    auto bias2 = [&](float(&b)[2], int l) {
+        const float* bias = a.weff + a.tb.boff[NET_C * LAYERS + l] + 64 * wave + (lane & 31);
+        b[0] = bias[0]; b[1] = bias[32];
+    };
+    auto epi_impl = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2], auto SAVE) {
         float* Hl = CH + (size_t)l * Mp * 256;
-        unsigned long long bits = 0;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            const float b = bias[col];
+        unsigned blo = 0, bhi = 0;
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+            add_bias4(v, bc[ni]);
+            unsigned m = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[i] = fmaxf(v[i] + b, 0.f);
-                bits |= (unsigned long long)(v[i] > 0.f) << (4 * qi + i);
+                m |= (v[i] > 0.f ? 1u : 0u) << (4 * (qi & 7) + i);
+                v[i] = relu1(v[i]);
             }
-            lds_store_quad(mainT, col, row, v);
-            if (save) g_store_quad(Hl, grow0, 256, row, col, v);
+            if (qi < 8) blo |= m; else bhi |= m;
+            lds_store_quad_at(mainT, off, v);
+            if (decltype(SAVE)::value) g_store_quad(Hl, grow0, 256, row, col, v);
         });
-        if (save)      // the ReLU masks of the backward sweep: 2 words per thread instead of 64 activations
-            reinterpret_cast<unsigned long long*>(wsb(a, WS_C_MASK))[((size_t)l * (Mp / 64) + tile) * 256 + tid] = bits;
+        if (decltype(SAVE)::value)      // the ReLU masks of the backward sweep: 2 words per thread instead of 64 activations
+            reinterpret_cast<unsigned long long*>(wsb(a, WS_C_MASK))[((size_t)l * (Mp / 64) + tile) * 256 + tid] = (unsigned long long)bhi << 32 | blo;
     };
+    auto epi = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2]) {
+        if (save) epi_impl(acc, l, bc, std::true_type{});
+        else epi_impl(acc, l, bc, std::false_type{});
+    };
+    float bc[2], bn[2];
+    bias2(bn, 0);
     {
         f32x16 acc[2][2];
         acc_zero(acc);
@@ -459,13 +519,17 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
         __syncthreads();
         gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF0F], 0, 2 * wave, lane);
         __syncthreads();
-        epi(acc, 0);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        bias2(bn, 1);
+        epi(acc, 0, bc);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
         f32x16 acc[2][2];
         acc_zero(acc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+        if (l < 7) bias2(bn, l + 1);
         if (l != 4) {
             const int seg = l < 4 ? CF1 + (l - 1) : CF5 + (l - 5);
             gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
@@ -481,7 +545,7 @@ __device__ __forceinline__ void color_fwd_tile(const FwdArgs& a, const int tile)
             gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[CF4F], 0, 2 * wave, lane);
         }
         __syncthreads();
-        epi(acc, l);
+        epi(acc, l, bc);
         __syncthreads();
     }
     smalln_partial<3>(mainT, a.weff + a.tb.woff[NET_C * LAYERS + 8], 256, red, tid);
