@@ -125,12 +125,15 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         });
     }
     __syncthreads();
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
     auto epi = [&](f32x16(&acc)[2][2], int l, unsigned long long bits) {   // acc = hbar_l ; ybar_{l-1} = relu'(.) * hbar_l
         float* Yl = CY + (size_t)(l - 1) * Mp * 256;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
+        const unsigned blo = (unsigned)bits, bhi = (unsigned)(bits >> 32);      // quads 0..7 | 8..15
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = ((bits >> (4 * qi + i)) & 1ull) ? v[i] : 0.f;
-            lds_store_quad(mainT, col, row, v);
+            for (int i = 0; i < 4; ++i) v[i] = keep_if_bit(v[i], qi < 8 ? blo : bhi, 4 * (qi & 7) + i);
+            lds_store_quad_at(mainT, off, v);
             g_store_quad(Yl, grow0, 256, row, col, v);
         });
     };
@@ -284,12 +287,14 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
             prefetch_half_f<decltype(NI)::value>(S, SACT + (size_t)l * Mp * 256, grow0, 2 * wave, lane);
             prefetch_half_f<decltype(NI)::value>(Rr, RHO + (size_t)l * Mp * 256, grow0, 2 * wave, lane);
             for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
-                float z2[4];
+                float z2[4], dphi[4];
+                softplus100_grad_from_s4(S[b8], dphi);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dphi = softplus100_grad_from_s(S[b8][i]);
-                    z2[i] = 100.f * (1.f - dphi) * Rr[b8][i] * v[i];        // softplus'' / softplus' = 100 (1 - softplus')
-                    v[i] = dphi * v[i];                                     // tau_{l+1}
+                for (int h = 0; h < 2; ++h) {      // packed pairs
+                    const f32x2p d = {dphi[2 * h], dphi[2 * h + 1]}, r = {Rr[b8][2 * h], Rr[b8][2 * h + 1]}, t = {v[2 * h], v[2 * h + 1]};
+                    const f32x2p zz = 100.f * (1.f - d) * r * t;            // softplus'' / softplus' = 100 (1 - softplus')
+                    const f32x2p tt = d * t;                                // tau_{l+1}
+                    z2[2 * h] = zz[0]; z2[2 * h + 1] = zz[1]; v[2 * h] = tt[0]; v[2 * h + 1] = tt[1];
                 }
                 lds_store_quad(mainT, col, row, v);
                 g_store_quad_f(TAU + (size_t)l * Mp * 256, grow0, row, col, v);
@@ -328,8 +333,14 @@ __device__ __forceinline__ void sdf_bwd_tile(const BwdArgs& a, const int tile) {
             prefetch_half_f<decltype(NI)::value>(S, SACT + (size_t)(l - 1) * Mp * 256, grow0, 2 * wave, lane);
             prefetch_half_f<decltype(NI)::value>(Z2, ZB + (size_t)(l - 1) * Mp * 256, grow0, 2 * wave, lane);
             for_quads_half<decltype(NI)::value>(acc, 2 * wave, lane, [&](int row, int col, float(&v)[4], int b8) {
+                float dphi[4];
+                softplus100_grad_from_s4(S[b8], dphi);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = softplus100_grad_from_s(S[b8][i]) * v[i] + Z2[b8][i];
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2p d = {dphi[2 * h], dphi[2 * h + 1]}, t = {v[2 * h], v[2 * h + 1]}, z = {Z2[b8][2 * h], Z2[b8][2 * h + 1]};
+                    const f32x2p o = d * t + z;
+                    v[2 * h] = o[0]; v[2 * h + 1] = o[1];
+                }
                 lds_store_quad(mainT, col, row, v);
                 g_store_quad_f(ZB + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
             });
@@ -470,18 +481,25 @@ __device__ __forceinline__ void deform_tan_tile(const BwdArgs& a, const int tile
         const int r = tid >> 2, c4 = tid & 3;
         for (int k = c4; k < 56; k += 4) T0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
-    auto epi = [&](f32x16(&acc)[2][2], int l, const MaskWords& mk) {
+    // (the skip layer's per-lane test is a compile-time instantiation behind a wave-uniform branch: see deform_fwd_tile)
+    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    auto epi_impl = [&](f32x16(&acc)[2][2], int l, const MaskWords& mk, auto SKIP) {
         float* Tl = T + (size_t)l * Mp * 256;
-        for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {
-            if (l == 3 && col >= 204) {
+        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+            if (decltype(SKIP)::value && col >= 204) {
                 lds_load_quad(aux, col - 204, row, v);          // IDR skip: next input = [h(204) | enc(52)]
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = mask_keep(v[i], mk, qi, i, hi);
             }
-            lds_store_quad(mainT, col, row, v);
+            lds_store_quad_at(mainT, off, v);
             g_store_quad(Tl, grow0, 256, row, col, v);
         });
+    };
+    auto epi = [&](f32x16(&acc)[2][2], int l, const MaskWords& mk) {
+        if (l == 3 && wave == 3) epi_impl(acc, l, mk, std::true_type{});
+        else epi_impl(acc, l, mk, std::false_type{});
     };
     {
         const MaskWords mk = load_mask_words(MK, tile, wave, lane);

@@ -214,7 +214,7 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
                     for (int i = 0; i < 4; ++i) v[i] = 0.f;          // layer 3 has 204 outputs
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = mask_bit(mk, qi, i, hi) ? v[i] : 0.f;
+                    for (int i = 0; i < 4; ++i) v[i] = mask_keep(v[i], mk, qi, i, hi);
                 }
                 lds_store_quad_at(mainT, off, v);
                 if (decltype(SAVE)::value) g_store_quad(Rl, grow0, 256, row, col, v);
@@ -353,8 +353,10 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
             f32x16 dummy[2][2];
             for_quads_off(dummy, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
                 const float4 t = *reinterpret_cast<const float4*>(mainT + off);
-                v[0] = softplus100_grad_from_s(t.x) * w8c[ni]; v[1] = softplus100_grad_from_s(t.y) * w8c[ni];
-                v[2] = softplus100_grad_from_s(t.z) * w8c[ni]; v[3] = softplus100_grad_from_s(t.w) * w8c[ni];
+                const float sv[4] = {t.x, t.y, t.z, t.w};
+                softplus100_grad_from_s4(sv, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= w8c[ni];
                 lds_store_quad_at(mainT, off, v);
                 if (decltype(SAVE)::value) g_store_quad_f(RHO + (size_t)7 * Mp * 256, grow0, row, col, v);
             });
@@ -380,8 +382,13 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         auto repi = [&](auto SAVE) {
             for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
                 const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+                float dphi[4];
+                softplus100_grad_from_s4(S[qi], dphi);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= softplus100_grad_from_s(S[qi][i]);
+                for (int h = 0; h < 2; ++h) {      // packed pairs
+                    const f32x2p o = f32x2p{v[2 * h], v[2 * h + 1]} * f32x2p{dphi[2 * h], dphi[2 * h + 1]};
+                    v[2 * h] = o[0]; v[2 * h + 1] = o[1];
+                }
                 lds_store_quad_at(mainT, off, v);
                 if (decltype(SAVE)::value) g_store_quad_f(RHO + (size_t)(l - 1) * Mp * 256, grow0, row, col, v);
             });
