@@ -192,7 +192,7 @@ __device__ __forceinline__ float keep_if_bit(float v, unsigned w, int k) {
 //    RTC*4 values per lane (they do not depend on the layer), the n-tile is an immediate offset -> RTC*4 pinned registers instead of
 //    ~7 VALU instructions per ds_write_b128;
 //  * the bias is requested a layer ahead and added as packed pairs (add_bias4).  (As the accumulators' INITIAL value it would cost
-//    nothing at all -- the chain kernels with continuous outputs may do that -- but the no-grad queries feed DISCRETE decisions, the first
+//    nothing at all, but the no-grad queries feed DISCRETE decisions, the first
 //    sign change of ray marching: a different rounding order moves a proposal that sits within 1e-7 of the surface to its other side,
 //    and the golden surface-neighbour case (tests/test_gpu_render.py::test_aux_forward) holds such a ray.)
 template <int RTC> struct QuadOff { int o[RTC * 4]; };
@@ -209,15 +209,6 @@ __device__ __forceinline__ QuadOff<RTC> quad_offsets(int rt0, int nt0, int lane)
             qo.o[ri * 4 + q] = v;
         }
     return qo;
-}
-template <int RTC, int NTC>
-__device__ __forceinline__ void acc_fill(f32x16 (&acc)[RTC][NTC], const float (&b)[NTC]) {
-#pragma unroll
-    for (int i = 0; i < RTC; ++i)
-#pragma unroll
-        for (int j = 0; j < NTC; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = b[j];
 }
 // f(row, col, v[4], off, ni): off = LDS float offset of the quad (see QuadOff), ni = n-tile index within the wave tile
 template <int RTC, int NTC, class F>
