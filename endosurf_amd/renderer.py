@@ -292,8 +292,9 @@ class EndoSurfNet(nn.Module):
         self._rebind()
 
     # ---- reference query surface (endosurf.py:570-689), evaluated by the fused HIP kernels -------------------------------------
-    # Differentiable w.r.t. the network PARAMETERS (hand-written backward) when grad mode is on; not w.r.t. the query points
-    # (the reference's callers never ask for that: its own uses are under no_grad or go through the renderer).
+    # Differentiable w.r.t. the network PARAMETERS (hand-written backward) when grad mode is on.  W.r.t. the query points: the sdf query to
+    # first order (its derivative IS g_o) and mixed with the parameters; nothing else (the reference's callers never ask for more: its own
+    # uses are under no_grad or go through the renderer) -- a RuntimeWarning says so once when points that require grad arrive.
     def _r(self):
         r = self._renderer() if getattr(self, "_renderer", None) is not None else None
         if r is None:
@@ -309,26 +310,53 @@ class EndoSurfNet(nn.Module):
         return x, (t.expand(x.shape[0]) if t.numel() == 1 else t).contiguous()
 
     def get_sdf_from_observed_space(self, x, t):
-        """sdf(x + deform(x, t)) [M,1]  (endosurf.py:570-579)."""
+        """sdf(x + deform(x, t)) [M,1]  (endosurf.py:570-579).
+
+        If ``x`` requires grad (the reference's own pattern around this call is ``autograd.grad(sdf, x, create_graph=True)``,
+        endosurf.py:585-600) the result is ALSO differentiable w.r.t. the points to first order: d sdf / d x is the kernels' g_o = J^T g_c,
+        attached as ``sdf + <x - x.detach(), g_o>`` (value unchanged).  g_o itself carries the hand-written backward to the parameters, so
+        a loss on ``autograd.grad(sdf, x, create_graph=True)`` (an eikonal term on arbitrary points) back-propagates to the parameters
+        exactly like the reference's; the second derivative w.r.t. the POINTS (a Hessian-vector product) is not available: g_o is a
+        constant w.r.t. x in that graph."""
         r = self._r()
         with torch.cuda.device(r.device):
+            x_in = x
             x, t = self._xt(x, t)
             weff, _ = r._weights()
-            if weff.requires_grad and torch.is_grad_enabled():
-                return r._point_eval(x, t)[0]
+            wrt_x = torch.is_tensor(x_in) and x_in.requires_grad and torch.is_grad_enabled()
+            if wrt_x or (weff.requires_grad and torch.is_grad_enabled()):
+                sdf, g_o = r._point_eval(x, t)
+                if wrt_x:
+                    xr = x_in.to(torch.float32).reshape(-1, 3)
+                    sdf = sdf + ((xr - xr.detach()) * g_o).sum(-1, keepdim=True)
+                return sdf
             return r.sdf_observed(x, t)
 
     def get_sdf_grad_from_observed_space(self, x, t):
-        """d sdf / d x at observed points [M,3] = J^T g_c  (endosurf.py:581-601)."""
+        """d sdf / d x at observed points [M,3] = J^T g_c  (endosurf.py:581-601).  Differentiable w.r.t. the parameters; a graph back to
+        the points (their Hessian) does not exist here -- asked for (``x.requires_grad``), that is said once instead of silently dropped."""
         r = self._r()
         with torch.cuda.device(r.device):
+            self._warn_points_detached(x, "get_sdf_grad_from_observed_space")
             x, t = self._xt(x, t)
             return r._point_eval(x, t)[1]
+
+    _warned_detached = set()
+
+    @classmethod
+    def _warn_points_detached(cls, x, what):
+        if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and what not in cls._warned_detached:
+            cls._warned_detached.add(what)
+            import warnings
+            warnings.warn(f"endosurf_amd: {what}: the query points require grad, but this output is differentiable w.r.t. the network "
+                          "parameters only (no second derivative w.r.t. the points: INTEGRATION.md); the points are treated as constants",
+                          RuntimeWarning, stacklevel=3)
 
     def get_sdf_grad_from_canonical_space(self, x):
         """d sdf / d x_c at canonical points [M,3]  (endosurf.py:603-619): the SDF network alone."""
         r = self._r()
         with torch.cuda.device(r.device):
+            self._warn_points_detached(x, "get_sdf_grad_from_canonical_space")
             x, t = self._xt(x, torch.zeros(1, device=x.device))
             return r._point_eval(x, t, canonical=True)[1]
 
@@ -354,6 +382,7 @@ class EndoSurfNet(nn.Module):
         """cat([sdf, rgb]) [M,4] for inputs [x, d, t] [M,7]  (endosurf.py:660-689)."""
         r = self._r()
         with torch.cuda.device(r.device):
+            self._warn_points_detached(inputs, "EndoSurfNet.forward")
             inp = inputs.detach().to(torch.float32).reshape(-1, 7)
             x, t = self._xt(inp[:, :3], inp[:, 6])
             d = inp[:, 3:6].contiguous()

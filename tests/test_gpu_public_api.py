@@ -115,6 +115,50 @@ def test_model_query_surface(name):
     assert gn is not None and float(gn.norm()) > 0
 
 
+@pytest.mark.parametrize("mode,use_deform", [("trained", True), ("trained", False)])
+def test_sdf_query_is_differentiable_wrt_points_first_order(mode, use_deform):
+    """The reference's own pattern around get_sdf_from_observed_space (endosurf.py:585-600): ``x.requires_grad_(True); sdf = model(x);
+    g = autograd.grad(sdf, x, create_graph=True)`` and a loss on g (an eikonal term on arbitrary points) back-propagated to the
+    parameters.  HIP: d sdf / d x = g_o of the fused kernels, whose own backward carries d g_o / d theta.  Checked against the fp64
+    oracle (autograd through the closed-form restatement): g, the loss, and the parameter gradients of sdf AND of the loss on g."""
+    import weightgen
+    from oracle import endosurf_oracle as O
+    seed, M = 11, 192
+    r = renderer_for(seed, mode, use_deform)
+    state = weightgen.make_state(seed, mode, use_deform)
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state.items()}
+    net = O.OracleNet(params, use_deform)
+    rng = np.random.default_rng(5)
+    x_np = rng.uniform(-0.8, 0.8, size=(M, 3)).astype(np.float32)
+    t_np = rng.uniform(0.0, 1.0, size=(M, 1)).astype(np.float32)
+
+    def run(sdf_fn, x, t):
+        sdf = sdf_fn(x, t)
+        (g,) = torch.autograd.grad(sdf, x, grad_outputs=torch.ones_like(sdf), create_graph=True)
+        loss = ((g.norm(dim=-1) - 1.0) ** 2).mean() + 0.3 * sdf.mean()
+        loss.backward()
+        return sdf.detach(), g.detach(), float(loss.detach())
+
+    x64 = torch.from_numpy(x_np).double().requires_grad_(True)
+    o_sdf, o_g, o_loss = run(net.sdf_observed, x64, torch.from_numpy(t_np).double())
+    for p in r.parameters():
+        p.grad = None
+    x32 = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    h_sdf, h_g, h_loss = run(r.model.get_sdf_from_observed_space, x32, torch.from_numpy(t_np).cuda())
+    assert float((h_sdf.double().cpu() - o_sdf).abs().max()) < 1e-5
+    assert float((h_g.double().cpu() - o_g).abs().max()) < 1e-4
+    assert abs(h_loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
+    # first-order gradient w.r.t. the points themselves: d loss / d x holds the sdf term's share only (g_o is a constant w.r.t. x here)
+    assert x32.grad is not None and float((x32.grad.double().cpu() - 0.3 / M * o_g).abs().max()) < 1e-6
+    named = dict(r.named_parameters())
+    keys = ["sdf_network.net.0.weight_v", "sdf_network.net.4.weight_g", "sdf_network.net.7.bias"] + (
+        ["deform_network.net.1.weight_v", "deform_network.net.6.bias"] if use_deform else [])
+    for k in keys:
+        gh, go = named["model." + k].grad.double().cpu(), params[k].grad
+        rel = float((gh - go).norm() / (go.norm() + 1e-30))
+        assert rel < 2e-3, (k, rel)
+
+
 def test_parameter_rebinding_is_detected():
     """Anything that gives a parameter its own storage (``p.data = ...`` loaders) is folded back into the flat buffer the kernels
     read, and ``.to()`` moves the flat buffer itself (stale-weights hazard)."""
