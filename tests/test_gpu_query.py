@@ -55,7 +55,7 @@ def _query(lib, _lib, packed, weff, use_deform, **kw):
 
 
 @pytest.mark.parametrize("mode,use_deform", [("init", True), ("trained", True), ("trained", False)])
-@pytest.mark.parametrize("M", [1, 64, 1000])
+@pytest.mark.parametrize("M", [1, 64, 1000, 12000, 20031])      # 16-point tiles (<= 9 216) | 32-point tiles (<= 16 384) | 64-point tiles, ragged
 def test_query_sdf_points(mode, use_deform, M):
     lib, _lib, state, flat, weff, packed, net = _setup(21, mode, use_deform)
     rng = np.random.default_rng(5 + M)
