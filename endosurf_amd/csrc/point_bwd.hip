@@ -28,12 +28,13 @@ extern "C" int es_debug_b_profile(long long* out, int n) { return (int)hipMemcpy
 
 // Two-segment launches as in point_fwd.hip: the tail's two dependent stages ride in the halves of the main deformation launch
 //   colour_bwd(main) | sdf_bwd(main) | sdf_bwd(tail) + deform_bwd(main, 1st half) | deform_bwd(tail) + deform_bwd(main, 2nd half)
-enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM, BB_TAN, BB_TAN_SDF };
+enum BwdBody { BB_NONE = 0, BB_COLOR, BB_SDF, BB_DEFORM, BB_TAN, BB_TAN_SDF, BB_DEFORM_HALF };
 template <int B>
 __device__ __forceinline__ void bwd_body(const BwdArgs& a, int tile) {
     if constexpr (B == BB_COLOR) color_bwd_tile(a, tile);
     else if constexpr (B == BB_SDF) sdf_bwd_tile(a, tile);
     else if constexpr (B == BB_DEFORM) deform_bwd_tile(a, tile);
+    else if constexpr (B == BB_DEFORM_HALF) deform_bwd_tile<true>(a, tile);      // 16-point tiles (the tail's stand-alone launch)
     else if constexpr (B == BB_TAN) deform_tan_tile(a, tile);
     else if constexpr (B == BB_TAN_SDF) {      // both stages of a colour-less tile in one workgroup (J gbar_o goes through the workspace)
         deform_tan_tile(a, tile);
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_point_bwd(BwdArgs a, int n0, in
     bwd_body<B1>(a, t1 + (int)blockIdx.x - n0);
 }
 constexpr int bwd_lds(int b) {
-    return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM ? DBWD_LDS_BYTES : (b == BB_TAN || b == BB_TAN_SDF ? LEAN_LDS_BYTES : 0)));
+    return b == BB_COLOR ? CBWD_LDS_BYTES : (b == BB_SDF ? SBWD_LDS_BYTES : (b == BB_DEFORM || b == BB_DEFORM_HALF ? DBWD_LDS_BYTES : (b == BB_TAN || b == BB_TAN_SDF ? LEAN_LDS_BYTES : 0)));
 }
 template <int B0, int B1>
 static int launch_bwd(const BwdArgs& a, int n0, int t0, int n1, int t1, hipStream_t st) {
@@ -95,7 +96,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
             if (int e = deform_tan_x3r(src, pr, weff, ws, a.L, d_go, st, Mc)) return e;
             { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
             if (int e = deform_bwd_x3r_with_tail(a, pr, Mc, st)) return e;
-            { ScopedTimer tm(KID_DEFORM_BWD, Mp - Mc, st); if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
+            { ScopedTimer tm(KID_DEFORM_BWD, Mp - Mc, st); if (int e = launch_bwd<BB_NONE, BB_DEFORM_HALF>(a, 0, 0, (Mp - Mc) / 16, Mc / 16, st)) return e; }
             return hip_last("point_backward_chains");
         }
         if (flags & PF_COLOR) { if (int e = color_bwd_x3r(src, pr, weff, ws, a.L, deform, a.M_color, d_rgb, st)) return e; }
@@ -113,7 +114,7 @@ int point_backward_chains(const PointSrc& src, const float* packed, const float*
         { ScopedTimer tm(KID_SDF_BWD, Mc, st); if (int e = launch_bwd<BB_NONE, BB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
         { ScopedTimer tm(KID_DEFORM_BWD, src.M, st);
           if (int e = launch_bwd<BB_TAN_SDF, BB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, Mc / 32, 0, st)) return e;
-          if (int e = launch_bwd<BB_NONE, BB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
+          if (int e = launch_bwd<BB_NONE, BB_DEFORM_HALF>(a, 0, 0, (Mp - Mc) / 16, Mc / 16, st)) return e; }      // half-height tiles
         return hip_last("point_backward_chains");
     }
     if (!deform && aux_tail(flags, a.M_color, src.M)) {

@@ -530,19 +530,27 @@ __device__ __forceinline__ void deform_tan_tile(const BwdArgs& a, const int tile
 // -------------------------------------------------------------------------------------------------------------
 // Deformation network, reverse sweep of the value row (seed xbar_c) and of the J d row (seed vbar from the colour network).
 // Tile = 32 points = 64 rows (row 2p = value, 2p + 1 = tangent).  LDS: activation tile + 768 B => two workgroups per CU.
+// HALF: 16 points = 32 rows per workgroup (the stand-alone launch of a training batch's tail runs at one tile's latency: see deform_fwd_tile).
 constexpr int DBWD_LDS_BYTES = (MAIN_FLOATS + 192) * 4;
+template <bool HALF = false>
 __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile) {
+    constexpr int PTS = HALF ? 16 : 32, RTC = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* a8 = lds + MAIN_FLOATS;   // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = tile * 32;
+    const int pt0 = tile * PTS;
     const size_t grow0 = (size_t)pt0 * 2;
     const size_t rows2 = (size_t)a.L.Mp * 2;
     const bool color = a.flags & PF_COLOR;
+    // this thread's mask word of layer l (its own word of the forward tile; a half tile owns 16 bits of the 32-point tile's word)
+    auto mask_word = [&](const unsigned* MK, size_t nt32, int l) -> unsigned {
+        if constexpr (HALF) return MK[((size_t)l * nt32 + (tile >> 1)) * 256 + tid] >> (16 * (tile & 1));
+        else return MK[((size_t)l * nt32 + tile) * 256 + tid];
+    };
 
-    if (tid < 64) {
+    if (tid < 2 * PTS) {
         const int p = tid >> 1, c = tid & 1;
         const size_t gp = (size_t)(pt0 + p);
         const bool has_v = color && pt0 + p < a.M_color;
@@ -560,8 +568,8 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
     float* DA = wsb(a, WS_D_A);
     {   // abar_7 = mask_7 * (W8^T abar_8)
         const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
-        const unsigned bits = MK[((size_t)7 * nt32 + tile) * 256 + tid];        // this thread's own word of the forward tile
-        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+        const unsigned bits = mask_word(MK, nt32, 7);
+        for_quads_noacc<RTC, 2>(0, 2 * wave, lane, [&](int row, int col) {
             const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
             const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
             const bool m0 = (bits >> (2 * qi)) & 1u, m2 = (bits >> (2 * qi + 1)) & 1u;   // value rows
@@ -575,11 +583,11 @@ __device__ __forceinline__ void deform_bwd_tile(const BwdArgs& a, const int tile
     __syncthreads();
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-        const unsigned bits = MK[((size_t)(l - 1) * nt32 + tile) * 256 + tid];        // in flight during the GEMM
-        f32x16 acc[2][2];
+        const unsigned bits = mask_word(MK, nt32, l - 1);        // in flight during the GEMM
+        f32x16 acc[RTC][2];
         acc_zero(acc);
-        if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
-        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
+        if (l == 3) gemm_seg<26, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
+        else gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
         __syncthreads();
         float* Al = DA + (size_t)(l - 1) * rows2 * 256;
         for_quads_qi(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int qi) {

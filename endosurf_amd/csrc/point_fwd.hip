@@ -23,10 +23,11 @@ namespace es {
 // kernels (1024 + 48 tiles), which costs a full tile time.  Every main launch of this workload is a whole number of rounds,
 // so extra tiles always cost something -- least inside a launch of MANY short rounds: the tail's two dependent stages
 // (deform, then SDF) are therefore mixed into the two halves of the 8-round deformation launch of the main tiles.
-enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP, FB_SDF_VJP };
+enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP, FB_SDF_VJP, FB_DEFORM_HALF };
 template <int B>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
     if constexpr (B == FB_DEFORM) deform_fwd_tile(a, tile);
+    else if constexpr (B == FB_DEFORM_HALF) deform_fwd_tile<true>(a, tile);      // 16-point tiles (the tail's stand-alone launch)
     else if constexpr (B == FB_SDF) sdf_fwd_tile(a, tile);
     else if constexpr (B == FB_COLOR) color_fwd_tile(a, tile);
     else if constexpr (B == FB_VJP) deform_vjp_tile(a, tile);
@@ -95,7 +96,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
             // dependent stages hidden in this family's 4-round launch (infer_x3r.hip k_deform_jvp_x3r_tail):
             //   deform(tail, fp32) | [sdf + vjp](tail, fp32) + jvp(main) | sdf(main, fp32) | colour(main) | vjp(main)
             const int Mc = a.M_color;
-            { ScopedTimer tm(KID_DEFORM_FWD, Mp - Mc, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e; }
+            { ScopedTimer tm(KID_DEFORM_FWD, Mp - Mc, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM_HALF>(a, 0, 0, (Mp - Mc) / 16, Mc / 16, st)) return e; }
             if (int e = deform_jvp_x3r_with_tail(a, pr, Mc, st)) return e;
             { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
             if (int e = color_fwd_x3r(src, pr, weff, ws, a.L, deform, Mc, true, st)) return e;
@@ -113,7 +114,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
         //   deform(tail) | [sdf + vjp](tail) + deform(main) | sdf(main) | colour(main) | vjp(main)
         const int Mc = a.M_color;
         { ScopedTimer tm(KID_DEFORM_FWD, src.M, st);
-          if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, (Mp - Mc) / 32, Mc / 32, st)) return e;
+          if (int e = launch_fwd<FB_NONE, FB_DEFORM_HALF>(a, 0, 0, (Mp - Mc) / 16, Mc / 16, st)) return e;      // at one tile's latency: half-height tiles
           if (int e = launch_fwd<FB_SDF_VJP, FB_DEFORM>(a, (Mp - Mc) / TM, Mc / TM, Mc / 32, 0, st)) return e; }
         { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
         { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }

@@ -27,7 +27,12 @@ __device__ __forceinline__ float* wsb(const FwdArgs& a, int buf) { return a.ws +
 // deformation network, value + forward-mode tangent along the ray direction d:  x_c = x + MLP(x, t) and v = J d.
 // Tile = 32 points = 64 rows (row 2p = value, row 2p + 1 = tangent).  The layer outputs u_1..u_8 are always streamed out:
 // their value rows are the ReLU masks of the VJP sweep below (inference writes only those rows).
+// HALF: 16 points = 32 rows per workgroup (row tile 0 of the same LDS layout; the GEMMs issue half the MFMAs) for the stand-alone launch of a
+// training batch's colour-less tail: 96 tiles run at ONE tile's latency whatever their number, so half the height is ~half the time
+// (0.16 -> 0.09 ms).  A half tile writes its 16 mask bits per thread into its half of the 32-point tile's word.
+template <bool HALF = false>
 __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile) {
+    constexpr int PTS = HALF ? 16 : 32, RTC = HALF ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;
@@ -38,12 +43,12 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     float* red = aux;        // [4][3][64]: the encoding rows are dead after layer 3's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt0 = tile * 32;
+    const int pt0 = tile * PTS;
     const size_t grow0 = (size_t)pt0 * 2;
     const bool save = a.flags & PF_SAVE;
     const size_t rows2 = (size_t)a.L.Mp * 2;
 
-    if (tid < 32) {
+    if (tid < PTS) {
         float x[3], t, d[3];
         load_point(a.src, pt0 + tid, x, t, d);
         px[tid] = x[0]; px[32 + tid] = x[1]; px[64 + tid] = x[2]; pt[tid] = t;
@@ -53,7 +58,7 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     __syncthreads();
     {   // encoding rows: value row 2p, tangent row 2p+1 = (d enc / d x) d; the time part has no tangent
         const int p = tid & 31;
-        for (int item = tid >> 5; item < 25; item += 8) {
+        for (int item = tid >> 5; item < 25 && p < PTS; item += 8) {
             if (item < 18) {
                 const int c = item % 3, i = item / 3;
                 const float f = (float)(1 << i);
@@ -81,7 +86,8 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     if (save) {   // u_0 rows for the weight-gradient GEMM: [2Mp][64], 56 columns written
         float* U0 = wsb(a, WS_D_U0);
         const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 56; k += 4) U0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+        if (r < 2 * PTS)
+            for (int k = c4; k < 56; k += 4) U0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
 
     float* U = wsb(a, WS_D_U);
@@ -91,12 +97,12 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
     // branch: the skip layer's copy (l == 3, columns >= 204: wave 3 only) is its own instantiation behind a wave-uniform test -- inside
     // one lambda it cost every quad of every layer an exec-mask branch and the phi moves behind it (708 -> ~300 instructions per layer
     // and wave) --, the bias is requested a layer ahead (two registers) and ``save`` is uniform.
-    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    const QuadOff<RTC> qo = quad_offsets<RTC>(0, 2 * wave, lane);
     auto bias2 = [&](float(&b)[2], int l) {
         const float* bias = a.weff + a.tb.boff[NET_D * LAYERS + l] + 64 * wave + (lane & 31);
         b[0] = bias[0]; b[1] = bias[32];
     };
-    auto epi_impl = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2], auto SKIP, auto SAVE) {
+    auto epi_impl = [&](f32x16(&acc)[RTC][2], int l, const float(&bc)[2], auto SKIP, auto SAVE) {
         float* Ul = U + (size_t)l * rows2 * 256;
         unsigned bits = 0;
         for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {       // rows: value, tangent, value, tangent
@@ -112,30 +118,32 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
             lds_store_quad_at(mainT, off, v);
             if (decltype(SAVE)::value) g_store_quad(Ul, grow0, 256, row, col, v);
         });
-        MK[((size_t)l * nt32 + tile) * 256 + tid] = bits;        // the masks of the VJP / tangent / reverse sweeps
+        // the masks of the VJP / tangent / reverse sweeps: one word per thread and 32-point tile (a half tile owns 16 bits of it)
+        if constexpr (HALF) reinterpret_cast<unsigned short*>(MK)[(((size_t)l * nt32 + (tile >> 1)) * 256 + tid) * 2 + (tile & 1)] = (unsigned short)bits;
+        else MK[((size_t)l * nt32 + tile) * 256 + tid] = bits;
     };
-    auto epi = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2], auto SKIP) {
+    auto epi = [&](f32x16(&acc)[RTC][2], int l, const float(&bc)[2], auto SKIP) {
         if (save) epi_impl(acc, l, bc, SKIP, std::true_type{});
         else epi_impl(acc, l, bc, SKIP, std::false_type{});
     };
     float bc[2], bn[2];
     bias2(bn, 0);
     {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         bc[0] = bn[0]; bc[1] = bn[1];
         bias2(bn, 1);
-        gemm_seg<7, 2, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
+        gemm_seg<7, RTC, 2>(acc, aux, a.packed + a.tb.segoff[DF0], 0, 2 * wave, lane);
         epi(acc, 0, bc, std::false_type{});
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         bc[0] = bn[0]; bc[1] = bn[1];
         if (l < 7) bias2(bn, l + 1);
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
+        gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[DF0 + l], 0, 2 * wave, lane);
         __syncthreads();
         if (l == 3 && wave == 3) epi(acc, l, bc, std::true_type{});
         else epi(acc, l, bc, std::false_type{});
@@ -147,7 +155,8 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
         const int i = tid >> 6, row = tid & 63, p = row >> 1, c = row & 1;
         const float val = smalln_reduce<3>(red, i, row);
         const size_t gp = (size_t)(pt0 + p);
-        if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 32 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
+        if (p >= PTS) {
+        } else if (c == 0) wsb(a, WS_XC)[gp * 3 + i] = px[i * 32 + p] + val + a.weff[a.tb.boff[NET_D * LAYERS + 8] + i];
         else wsb(a, WS_V)[gp * 3 + i] = val + pd[i * 32 + p];          // J d = d + (d Delta x / d x) d
     }
 }
