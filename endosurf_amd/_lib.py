@@ -61,6 +61,7 @@ PROTOTYPES = {
     "es_weightnorm_pack": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_weightnorm_backward": (C.c_int, [_c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
     "es_query_sdf": (C.c_int, [C.POINTER(es_points), _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_void_p]),
+    "es_query_sdf_tiles": (C.c_int, [C.POINTER(es_points), _c_float_p, _c_float_p, _c_float_p, C.c_int, C.c_int, C.c_void_p]),
     "es_packed_x3_bytes": (C.c_int64, []),
     "es_pack_x3": (_I, [_P, _P, _I, _P]),
     "es_query_sdf_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P, _I, _P]),
@@ -108,7 +109,8 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+QUERY_TILES_RACING = 32768      # include/endosurf_hip.h ES_QUERY_TILES_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 

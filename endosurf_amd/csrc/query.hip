@@ -176,13 +176,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
+// small_tiles_max: batches up to this many points run the 16-point tiles of query16.hip; 0 = the default (9 216: the up-sampling queries
+// of 1 024 rays and the secant iterations, batches that are latency-bound on their own).  A caller whose query SHARES the GPU with another
+// chain of small launches passes more (QUERY_TILES_RACING): the 32 768-point coarse query of a training step takes 0.48 ms on 64-point
+// tiles and 0.59 ms on 16-point tiles when it runs alone, but next to the secant iterations its 512 long tiles hold every workgroup slot
+// for half a millisecond while 2 048 short ones turn the slots over every ~75 us (the racing chains: 1.42 -> 1.37 ms, step -0.10 ms).
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
-              int ld_out, const int* ray_done) {
+              int ld_out, const int* ray_done, int small_tiles_max) {
 #ifdef ES_DEV_SWITCHES      // dev builds only (-DES_DEV_SWITCHES): A/B runs of the tile-height threshold
-    static const int q16_max = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 8192;
+    static const int q16_env = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 0;
+    const int q16_max = q16_env > 0 ? q16_env : (small_tiles_max > 0 ? small_tiles_max : 9216);
 #else
-    constexpr int q16_max = 9216;         // batches up to here are latency-bound: 16-point tiles (query16.hip); 8 192 = the up-sampling
-                                          // queries of 1 024 rays, + 1 024 = room for a secant iteration in the same grid (tools/front_end_times.py)
+    const int q16_max = small_tiles_max > 0 ? small_tiles_max : 9216;
 #endif
     if (src.M > 0 && src.M <= q16_max && ld_out == 0 && ray_done == nullptr)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches

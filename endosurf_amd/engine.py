@@ -206,11 +206,16 @@ class Engine:
         # there (0.27 vs 0.21 ms at 8 192 points, 0.27 vs 0.17 at 1 024: DESIGN 4, round 3), so the threshold stays above them
         return self.split_precision and M >= self.x3_query_min
 
-    def query_sdf(self, pts: es_points, weff, packed, use_deform: bool) -> torch.Tensor:
+    def query_sdf(self, pts: es_points, weff, packed, use_deform: bool, small_tiles_max: int = 0) -> torch.Tensor:
+        """``small_tiles_max``: batches up to this size on 16-point tiles (0 = the library's default; es_query_sdf_tiles)."""
         out = self.empty(pts.M)
         if self._use_x3(pts.M):
             check(self.lib.es_query_sdf_x3(C.byref(pts), ptr(self.packed_x3(weff, use_deform)), ptr(weff), ptr(out), 0, None, int(use_deform),
                                            self.st()), "es_query_sdf_x3")
+            return out
+        if small_tiles_max:
+            check(self.lib.es_query_sdf_tiles(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), int(small_tiles_max), self.st()),
+                  "es_query_sdf_tiles")
             return out
         check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), self.st()), "es_query_sdf")
         return out
@@ -225,9 +230,10 @@ class Engine:
         return near, far
 
     def sample_z(self, rays, u_perturb, weff, packed, use_deform, n_samples, n_importance, up_sample_steps, upsample: bool,
-                 trace: Optional[list] = None):
+                 trace: Optional[list] = None, racing: bool = False):
         """Coarse sampling + SDF-guided hierarchical up-sampling (reference render_rays, endosurf.py:71-110).
-        Returns z [N, S] (S = n_samples (+ n_importance))."""
+        Returns z [N, S] (S = n_samples (+ n_importance)).  ``racing``: this chain shares the GPU with another chain of small launches
+        (the secant iterations of a training step): its coarse query runs on 16-point tiles (es_query_sdf_tiles)."""
         N = rays.shape[0]
         n = n_samples
         sample_dist = 2.0 / n_samples
@@ -241,7 +247,8 @@ class Engine:
             return zc
         n_imp = n_importance // up_sample_steps
         zn = self.empty(N, S)
-        sdf_c = self.query_sdf(self.points(rays=rays, z=zc, n_per_ray=n, ldz=S), weff, packed, use_deform).view(N, n)
+        sdf_c = self.query_sdf(self.points(rays=rays, z=zc, n_per_ray=n, ldz=S), weff, packed, use_deform,
+                               small_tiles_max=_lib.QUERY_TILES_RACING if racing else 0).view(N, n)
         ld_sdf = n
         sdf_a, sdf_b = self.empty(N, S), self.empty(N, S)
         src = self.empty(N, S, dtype=torch.int32)

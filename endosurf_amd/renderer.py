@@ -680,8 +680,9 @@ class EndoSurfRenderer(nn.Module):
         return self.render_rays(rays, **kwargs)
 
     @_on_device
-    def sample_z(self, rays, iter_step=0, perturb_overwrite=None, u_perturb=None):
-        """Sampling stage of render_rays (endosurf.py:63-110): coarse samples + SDF-guided up-sampling, no grad. -> z_vals [N, S]"""
+    def sample_z(self, rays, iter_step=0, perturb_overwrite=None, u_perturb=None, racing=False):
+        """Sampling stage of render_rays (endosurf.py:63-110): coarse samples + SDF-guided up-sampling, no grad. -> z_vals [N, S]
+        ``racing``: issued on a stream that shares the GPU with another chain of small launches (engine.sample_z)."""
         rays = self._rays32(rays)
         weff, packed = self._weights()
         perturb = self.perturb if perturb_overwrite is None else perturb_overwrite
@@ -692,7 +693,7 @@ class EndoSurfRenderer(nn.Module):
         upsample = iter_step >= self.important_begin_iter and self.n_importance > 0
         with torch.no_grad():
             return self.engine.sample_z(rays, u, weff.detach(), packed, self.use_deform, self.n_samples, self.n_importance,
-                                        self.up_sample_steps, upsample)
+                                        self.up_sample_steps, upsample, racing=racing)
 
     def _rays_from(self, rays_o, rays_d, time=None):
         n = rays_o.shape[0]
