@@ -110,7 +110,7 @@ PROTOTYPES = {
 }
 
 ABI_VERSION = 6
-QUERY_TILES_RACING = 32768      # include/endosurf_hip.h ES_QUERY_TILES_RACING
+QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 

@@ -12,7 +12,7 @@ namespace es {
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st);
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
-              int ld_out = 0, const int* ray_done = nullptr, int small_tiles_max = 0);
+              int ld_out = 0, const int* ray_done = nullptr, int tile_points = 0);
 int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st);
 size_t packed_x3_bytes();
 int pack_x3(const float* weff, void* packed_x3, int use_deform, hipStream_t st);
@@ -137,12 +137,12 @@ int es_query_sdf(const es_points* pts, const float* packed, const float* weff, f
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
     return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream);
 }
-int es_query_sdf_tiles(const es_points* pts, const float* packed, const float* weff, float* sdf_out, int use_deform, int small_tiles_max,
+int es_query_sdf_tiles(const es_points* pts, const float* packed, const float* weff, float* sdf_out, int use_deform, int tile_points,
                        void* stream) {
     if (int e = check_src(pts)) return e;
     ES_REQUIRE(packed && weff && (sdf_out || pts->M == 0), "null buffer");
-    ES_REQUIRE(small_tiles_max >= 0, "small_tiles_max: 0 (default) or the largest batch that runs 16-point tiles");
-    return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream, 0, nullptr, small_tiles_max);
+    ES_REQUIRE(tile_points == 0 || tile_points == 16 || tile_points == 32 || tile_points == 64, "tile_points: 0 (by batch size), 16, 32 or 64");
+    return query_sdf(to_src(pts), packed, weff, sdf_out, use_deform, (hipStream_t)stream, 0, nullptr, tile_points);
 }
 int es_query_sdf_rays(const es_points* pts, const float* packed, const float* weff, float* sdf_out, int ld_out, const int* ray_done,
                       int use_deform, void* stream) {

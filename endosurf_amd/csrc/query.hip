@@ -176,20 +176,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
 
-// small_tiles_max: batches up to this many points run the 16-point tiles of query16.hip; 0 = the default (9 216: the up-sampling queries
-// of 1 024 rays and the secant iterations, batches that are latency-bound on their own).  A caller whose query SHARES the GPU with another
-// chain of small launches passes more (QUERY_TILES_RACING): the 32 768-point coarse query of a training step takes 0.48 ms on 64-point
-// tiles and 0.59 ms on 16-point tiles when it runs alone, but next to the secant iterations its 512 long tiles hold every workgroup slot
-// for half a millisecond while 2 048 short ones turn the slots over every ~75 us (the racing chains: 1.42 -> 1.37 ms, step -0.10 ms).
+// tile_points: 0 = chosen by the batch size (<= 9 216 points: the 16-point tiles of query16.hip -- the up-sampling queries of 1 024 rays and
+// the secant iterations are latency-bound on their own; <= 16 384: 32-point tiles, fewer than one 64-point tile per CU otherwise; above: 64),
+// or 16 / 32 / 64 as the caller says.  A caller whose query SHARES the GPU with another chain of small launches asks for shorter tiles than
+// the batch size alone suggests: the 32 768-point coarse query of a training step takes 0.48 ms on 512 64-point tiles when it runs alone,
+// but next to the secant iterations those hold every workgroup slot for half a millisecond, while 1 024 32-point tiles turn the slots over
+// twice as often (racing chains 1.42 -> 1.35 ms; 16-point tiles: 1.37 ms).
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
-              int ld_out, const int* ray_done, int small_tiles_max) {
+              int ld_out, const int* ray_done, int tile_points) {
+    int tp = tile_points ? tile_points : (src.M <= 9216 ? 16 : (src.M <= 16384 ? 32 : 64));
 #ifdef ES_DEV_SWITCHES      // dev builds only (-DES_DEV_SWITCHES): A/B runs of the tile-height threshold
     static const int q16_env = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 0;
-    const int q16_max = q16_env > 0 ? q16_env : (small_tiles_max > 0 ? small_tiles_max : 9216);
-#else
-    const int q16_max = small_tiles_max > 0 ? small_tiles_max : 9216;
+    if (q16_env > 0 && !tile_points) tp = src.M <= q16_env ? 16 : tp;
 #endif
-    if (src.M > 0 && src.M <= q16_max && ld_out == 0 && ray_done == nullptr)
+    if (tp == 16 && !(ld_out == 0 && ray_done == nullptr)) tp = 32;      // (the 16-point kernel writes flat outputs only)
+    if (src.M > 0 && tp == 16)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
     static DeviceOnce attr_done;
     if (attr_done.first()) {
@@ -201,7 +202,7 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     }
     if (src.M <= 0) return ST_OK;
     const Tabs tb = make_tabs();
-    const bool half = src.M <= 16384;      // fewer than one 64-point tile per CU: halve the tile instead of idling CUs
+    const bool half = tp == 32;
     const int pts = half ? 32 : 64;
     const dim3 grid((src.M + pts - 1) / pts), block(NTHREADS);
     const float4* pk = reinterpret_cast<const float4*>(packed);

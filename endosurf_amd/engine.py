@@ -206,15 +206,15 @@ class Engine:
         # there (0.27 vs 0.21 ms at 8 192 points, 0.27 vs 0.17 at 1 024: DESIGN 4, round 3), so the threshold stays above them
         return self.split_precision and M >= self.x3_query_min
 
-    def query_sdf(self, pts: es_points, weff, packed, use_deform: bool, small_tiles_max: int = 0) -> torch.Tensor:
-        """``small_tiles_max``: batches up to this size on 16-point tiles (0 = the library's default; es_query_sdf_tiles)."""
+    def query_sdf(self, pts: es_points, weff, packed, use_deform: bool, tile_points: int = 0) -> torch.Tensor:
+        """``tile_points``: 16 / 32 / 64 points per workgroup, 0 = the library's choice by batch size (es_query_sdf_tiles)."""
         out = self.empty(pts.M)
         if self._use_x3(pts.M):
             check(self.lib.es_query_sdf_x3(C.byref(pts), ptr(self.packed_x3(weff, use_deform)), ptr(weff), ptr(out), 0, None, int(use_deform),
                                            self.st()), "es_query_sdf_x3")
             return out
-        if small_tiles_max:
-            check(self.lib.es_query_sdf_tiles(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), int(small_tiles_max), self.st()),
+        if tile_points:
+            check(self.lib.es_query_sdf_tiles(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), int(tile_points), self.st()),
                   "es_query_sdf_tiles")
             return out
         check(self.lib.es_query_sdf(C.byref(pts), ptr(packed), ptr(weff), ptr(out), int(use_deform), self.st()), "es_query_sdf")
@@ -233,7 +233,7 @@ class Engine:
                  trace: Optional[list] = None, racing: bool = False):
         """Coarse sampling + SDF-guided hierarchical up-sampling (reference render_rays, endosurf.py:71-110).
         Returns z [N, S] (S = n_samples (+ n_importance)).  ``racing``: this chain shares the GPU with another chain of small launches
-        (the secant iterations of a training step): its coarse query runs on 16-point tiles (es_query_sdf_tiles)."""
+        (the secant iterations of a training step): its coarse query runs on 32-point tiles (es_query_sdf_tiles)."""
         N = rays.shape[0]
         n = n_samples
         sample_dist = 2.0 / n_samples
@@ -247,8 +247,9 @@ class Engine:
             return zc
         n_imp = n_importance // up_sample_steps
         zn = self.empty(N, S)
+        # (racing: never TALLER than 32 points -- a batch the library would give 16- or 32-point tiles anyway keeps the library's choice)
         sdf_c = self.query_sdf(self.points(rays=rays, z=zc, n_per_ray=n, ldz=S), weff, packed, use_deform,
-                               small_tiles_max=_lib.QUERY_TILES_RACING if racing else 0).view(N, n)
+                               tile_points=_lib.QUERY_TILE_RACING if racing and N * n > 16384 else 0).view(N, n)
         ld_sdf = n
         sdf_a, sdf_b = self.empty(N, S), self.empty(N, S)
         src = self.empty(N, S, dtype=torch.int32)

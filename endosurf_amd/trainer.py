@@ -60,7 +60,7 @@ def compute_loss_fused(renderer, batch: Dict[str, torch.Tensor], iter_step: int,
     ms = renderer._march_begin(rays)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb, racing=True)      # (short tiles for its coarse query: it races the secant)
+        z = renderer.sample_z(rays, iter_step, u_perturb=u_perturb, racing=True)      # (shorter tiles for its coarse query: it races the secant)
     d_i = renderer._march_refine(ms)
     aux_x, aux_t, valid_sn = renderer._train_aux_points(rays, depth_gt, mask_gt, d_i, surf_neig_rad, u_neigh)    # one launch
     eod_pts = aux_x[:N]

@@ -49,6 +49,9 @@ def test_flat_adam_training_matches_torch_adam():
     finals, first = [], []
     for flat in (True, False):
         r = renderer_for_case(c)
+        # fixed-order reductions: with fp32 atomics the two runs' gradients differ by their own run-to-run noise, which the normalised
+        # first Adam step turns into up to lr-sized differences for elements whose gradient is ~0 (1 run in 4 exceeded the 2 % allowance)
+        r.engine.deterministic = True
         tr = Trainer(r, lr=1e-3, flat_adam=flat)
         assert isinstance(tr.optimizer, FlatAdam) == flat
         for it in range(3):

@@ -49,8 +49,8 @@ def _query(lib, _lib, packed, weff, use_deform, **kw):
     for k in ("x", "t", "dirs", "rays", "z"):
         setattr(pts, k, _lib.ptr(kw[k]) if kw.get(k) is not None else None)
     pts.mode, pts.t_scalar, pts.n_per_ray, pts.ldz, pts.M = kw.get("mode", 0), kw.get("t_scalar", 0), kw.get("n_per_ray", 1), kw.get("ldz", 1), M
-    if kw.get("small_tiles_max"):
-        _lib.check(lib.es_query_sdf_tiles(C.byref(pts), _lib.ptr(packed), _lib.ptr(weff), _lib.ptr(out), int(use_deform), int(kw["small_tiles_max"]),
+    if kw.get("tile_points"):
+        _lib.check(lib.es_query_sdf_tiles(C.byref(pts), _lib.ptr(packed), _lib.ptr(weff), _lib.ptr(out), int(use_deform), int(kw["tile_points"]),
                                           _lib.stream_ptr()), "es_query_sdf_tiles")
     else:
         _lib.check(lib.es_query_sdf(C.byref(pts), _lib.ptr(packed), _lib.ptr(weff), _lib.ptr(out), int(use_deform), _lib.stream_ptr()), "es_query_sdf")
@@ -79,21 +79,22 @@ def test_query_sdf_points(mode, use_deform, M):
 
 
 def test_query_sdf_tiles_choice_of_tile_height():
-    """es_query_sdf_tiles (ABI v6): the caller's tile height.  20 031 ray samples on 16-point tiles (small_tiles_max = ES_QUERY_TILES_RACING)
-    and on the default 64-point tiles: both within the fp32 budget of the fp64 oracle, and within 2e-6 of each other (summation order)."""
-    from endosurf_amd._lib import QUERY_TILES_RACING
+    """es_query_sdf_tiles (ABI v6): the caller's tile height.  20 031 points on 16-, 32- and 64-point tiles: each within the fp32 budget of
+    the fp64 oracle, within 2e-6 of each other (summation order), the 64-point choice bit-identical to es_query_sdf's own."""
     lib, _lib, state, flat, weff, packed, net = _setup(23, "trained", True)
     rng = np.random.default_rng(9)
     M = 20031
     x = torch.from_numpy(rng.uniform(-0.8, 0.8, size=(M, 3)).astype(np.float32))
     t = torch.from_numpy(rng.uniform(size=(M,)).astype(np.float32))
-    a = _query(lib, _lib, packed, weff, True, x=x.cuda(), t=t.cuda(), M=M)
-    b = _query(lib, _lib, packed, weff, True, x=x.cuda(), t=t.cuda(), M=M, small_tiles_max=QUERY_TILES_RACING)
+    auto = _query(lib, _lib, packed, weff, True, x=x.cuda(), t=t.cuda(), M=M)
+    got = {tp: _query(lib, _lib, packed, weff, True, x=x.cuda(), t=t.cuda(), M=M, tile_points=tp) for tp in (16, 32, 64)}
     with torch.no_grad():
         ref = net.sdf_observed(x.double(), t.double()[:, None])[:, 0]
-    assert (a.double() - ref).abs().max().item() < 1e-5 and (b.double() - ref).abs().max().item() < 1e-5
-    assert (a - b).abs().max().item() < 2e-6
-    assert not torch.equal(a, b)          # (two different kernels did run)
+    for tp, v in got.items():
+        assert (v.double() - ref).abs().max().item() < 1e-5, tp
+        assert (v - auto).abs().max().item() < 2e-6, tp
+    assert torch.equal(got[64], auto) and torch.equal(got[32], got[64])          # 32- and 64-point tiles: the same MFMA order per row
+    assert not torch.equal(got[16], auto)                                         # (the 16-point kernel did run)
 
 
 def test_query_sdf_ray_samples_golden():

@@ -49,7 +49,7 @@ out["sampling_chain_alone_ms"] = timed(lambda: r.sample_z(rays, 1))
 def both():
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        r.sample_z(rays, 1, racing=True)          # as trainer.compute_loss_fused issues it (coarse query on 16-point tiles)
+        r.sample_z(rays, 1, racing=True)          # as trainer.compute_loss_fused issues it (coarse query on 32-point tiles)
     r._march_refine(ms)
     main.wait_stream(side)
 
