@@ -80,3 +80,11 @@ def test_bad_arguments_return_error_codes(lib):
     assert lib.es_query_sdf(C.byref(p), None, None, None, 1, None) == 1      # null x/t
     p.mode = 3
     assert lib.es_query_sdf(C.byref(p), None, None, None, 1, None) == 1
+    # es_query_sdf_tiles (ABI v6): the tile height is 0 (by batch size), 16, 32 or 64 -- checked before anything is launched
+    import numpy as np
+    buf = np.zeros(64, np.float32)
+    q = _lib.es_points()
+    q.M, q.mode, q.t_scalar = 4, 0, 1
+    q.x, q.t = buf.ctypes.data, buf.ctypes.data          # (host addresses: never dereferenced, the call fails on its argument check)
+    assert lib.es_query_sdf_tiles(C.byref(q), buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, 1, 24, None) == 1
+    assert b"tile_points" in lib.es_last_error()
