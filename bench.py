@@ -155,8 +155,12 @@ def cpu_baseline(n_rays=1024, min_seconds=10.0, max_iters=40, threads=16, extra_
 
 def pmc_info(symbol):
     """Counters of a kernel symbol from the newest committed rocprofv3 PMC summary that has it (profiles/*_pmc_summary.json; separate
-    --pmc passes, tools/pmc_summary.py), over all its launch sizes: HBM bytes per logical launch (FETCH_SIZE x 2 + WRITE_SIZE),
-    cycle-weighted MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)) and cycles per logical launch; None if absent."""
+    --pmc passes, tools/pmc_summary.py).  A summary row is one (instantiation, grid size) of the symbol with its launch count; a symbol
+    may have several (k_query_sdf: the 131 072-point marching query on 64-point tiles and the 32 768-point coarse query on 32-point
+    tiles).  Every figure returned is PER SINGLE LAUNCH, as a launch-weighted mean over the rows -- the same mix ``avg_launch_ms`` of the
+    live timers averages over (each step launches every row's kernel as often as the profiled steps did): HBM bytes (FETCH_SIZE x 2 +
+    WRITE_SIZE), cycles, cycle-weighted MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)); ``rows`` keeps the
+    per-(instantiation, grid) figures.  None if no summary has the symbol."""
     import glob
     # newest summary that has the symbol (by name: the round tags sort; mtimes are meaningless on a fresh copy of the tree)
     rows, used = [], None
@@ -167,15 +171,25 @@ def pmc_info(symbol):
             break
     if not rows:
         return None
-    # one timed launch may be two kernels (the halves of the deformation launch, point_fwd.hip): per logical launch =
-    # totals / launches of the most frequent instantiation
-    by_kernel = {}
-    for r in rows:
-        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0) + r["launches"]
-    n = max(by_kernel.values())
+    n = sum(r["launches"] for r in rows)
     cyc = sum(r["cycles"] * r["launches"] for r in rows)
     return dict(hbm_bytes=sum(r["hbm_bytes"] * r["launches"] for r in rows) / n, cycles=cyc / n,
-                mfma_util=sum(r["mfma_util"] * r["cycles"] * r["launches"] for r in rows) / cyc if cyc else None, source=os.path.basename(used))
+                mfma_util=sum(r["mfma_util"] * r["cycles"] * r["launches"] for r in rows) / cyc if cyc else None,
+                launches=n, source=os.path.basename(used),
+                rows=[dict(kernel=r["kernel"], grid_threads=r["grid_threads"], launches=r["launches"], cycles=r["cycles"],
+                           mfma_util=r["mfma_util"], hbm_bytes=r["hbm_bytes"]) for r in rows])
+
+
+def pmc_rates(pm, avg_launch_ms):
+    """(hbm_gbps, clock_ghz) that the committed counters mean at the launch duration measured live, or (None, None) with a reason when
+    either falls outside what the part can do (shader clock 1.0 - 2.6 GHz, HBM <= 8 000 GB/s): a counter summary of another build or
+    another launch mix must not print an impossible figure next to the measured ones (VERDICT r4 weak #7)."""
+    gbps = pm["hbm_bytes"] / (avg_launch_ms * 1e-3) / 1e9
+    ghz = pm["cycles"] / (avg_launch_ms * 1e-3) / 1e9
+    if not (1.0 <= ghz <= 2.6) or gbps > 8000.0:
+        return None, None, ("withheld: the committed counters (%s) and the live launch time disagree (%.2f GHz, %.0f GB/s): different "
+                            "build or launch mix" % (pm["source"], ghz, gbps))
+    return gbps, ghz, None
 
 
 def pmc_traffic(symbol):
@@ -350,6 +364,19 @@ class Workload:
         dt = time.perf_counter() - t0
         return self.ctx.max_over_ranks(dt), dt
 
+    def host_issue_ms(self, first, n=5):
+        """CPU time to ENQUEUE one step (no synchronisation inside; the queue is drained before each sample so that no launch call blocks
+        on a full queue): what the host must sustain per step for the GPU never to wait for it.  Median of n."""
+        import torch
+        ts = []
+        for i in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.step(first + i)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            torch.cuda.synchronize()
+        return sorted(ts)[len(ts) // 2]
+
     def measure(self, warmup, steps, timing_steps=3, early_exit_extra=True):
         """warm-up, the timed region, (train) the same step with the marching early exit, then a few instrumented steps."""
         eng, mode = self.eng, self.mode
@@ -372,6 +399,8 @@ class Workload:
                          note="results bit-identical to the headline step; on this synthetic init-weight scene every ray's first sign change "
                               "falls in the first block of 32 proposals (best case)")
             eng.march_block = 0
+        issue_ms = self.host_issue_ms(nxt) if mode != "frame" else None
+        nxt += 5
         self.use_graph = False         # (events cannot be recorded inside a captured graph: the per-kernel timers run on eager steps)
         rec = self.ctx.rank == 0       # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 records
         if mode == "frame":
@@ -388,8 +417,10 @@ class Workload:
             flops_per_step = timing.get("flops_per_step", 0.0)
         eng.march_block = march_block
         self.use_graph = self.graph
+        per = timing.get("per_step_ms")
         return dict(dt=dt, dt_local=dt_local, steps=steps, warmup=warmup, ms=dt / steps * 1e3, value=self.rays_per_step_job * steps / dt,
-                    with_early_exit=extra, timing=timing, flops_per_step=flops_per_step, next_step=nxt + 64 + timing_steps)
+                    with_early_exit=extra, timing=timing, flops_per_step=flops_per_step, next_step=nxt + 64 + timing_steps,
+                    host_issue_ms=issue_ms, sum_timed_kernel_ms=(sum(per.values()) if per and mode != "frame" else None))
 
     def roofline(self, m, full=True):
         timing, ms, flops_per_step = m["timing"], m["ms"], m["flops_per_step"]
@@ -399,6 +430,7 @@ class Workload:
         pm = pmc_info(d["kernel"])
         same_as_pmc = self.mode == "train" and self.config_id == 2 and not self.rays_override
         tr = (pm["hbm_bytes"], pm["source"]) if pm else None
+        gbps, ghz, withheld = pmc_rates(pm, d["avg_launch_ms"]) if pm and same_as_pmc else (None, None, None)
         e2e = flops_per_step / (ms * 1e-3) / 1e12
         e2e_nom = timing.get("nominal_flops_per_step", 0.0) * (flops_per_step / max(timing.get("flops_per_step", 0.0), 1e-30)) / (ms * 1e-3) / 1e12
         x3 = "_x3" in d["kernel"]
@@ -410,8 +442,10 @@ class Workload:
                         end_to_end=dict(achieved=round(e2e, 2), frac=round(e2e / PEAK_F32_MFMA, 4), unit="TFLOP/s (executed, fp32-equivalent) of the fp32 MFMA peak"),
                         pipes=timing.get("pipes") if self.split else None)
         return dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-                    traffic=tr[0] if tr else None, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                    traffic_source=tr[1] if tr else None, kernel=d["kernel"],
+                    traffic=tr[0] if tr else None,
+                    traffic_unit="HBM bytes per SINGLE launch of the symbol (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; launch-weighted mean over "
+                                 "its instantiations / grid sizes: traffic_rows)",
+                    traffic_source=tr[1] if tr else None, traffic_rows=pm["rows"] if pm else None, kernel=d["kernel"],
                     work="EXECUTED MACs (the MACs the kernel issues; kernel_macs in bench.py) x 2 x points per launch",
                     nominal=dict(achieved=d["nominal_tflops"] * (6.0 if x3 else 1.0), frac=d["nominal_tflops"] * (6.0 if x3 else 1.0) / peak,
                                  flops_per_launch=d["nominal_flops_per_launch"],
@@ -420,8 +454,7 @@ class Workload:
                     # the HBM rate its traffic means at the launch duration measured here
                     # (rates only where the PMC passes profiled this very workload: the headline configuration)
                     mfma_util=pm["mfma_util"] if pm else None,
-                    hbm_gbps=(pm["hbm_bytes"] / (d["avg_launch_ms"] * 1e-3) / 1e9) if pm and same_as_pmc else None,
-                    clock_ghz_from_pmc_cycles=(pm["cycles"] / (d["avg_launch_ms"] * 1e-3) / 1e9) if pm and same_as_pmc else None,
+                    hbm_gbps=gbps, clock_ghz_from_pmc_cycles=ghz, pmc_rates_note=withheld,
                     kernel_choice=("the kernel SYMBOL with the largest total time per step (all its launch sizes together)"
                                    + (" among the kernels on the bf16 matrix pipes (split-precision mode; roofline.pipes has both pipes)" if self.split else "")),
                     avg_launch_ms=d["avg_launch_ms"], launches=d["launches"], flops_per_launch=d["flops_per_launch"],
@@ -490,7 +523,7 @@ def run_extras(ctx, args, partial):
     over the ranks + one all-gather).  ``partial`` is filled as the extras finish (the watchdog prints what is there)."""
     import torch
     short = args.steps < 10          # (tests run the command with a handful of steps)
-    plan = [("forward", dict(config_id=2, mode="forward"), 3, 5 if short else 20, 3),
+    plan = [("forward", dict(config_id=2, mode="forward"), 10, 5 if short else 20, 3),
             ("split_precision_train", dict(config_id=2, mode="train", split=True), 3, 5 if short else 20, 3),
             ("cfg3", dict(config_id=3, mode="train"), 2, 3 if short else 10, 2),
             ("cfg4", dict(config_id=4, mode="train"), 3, 5 if short else 20, 3),
@@ -516,7 +549,10 @@ def run_extras(ctx, args, partial):
             if ctx.rank == 0:
                 partial[name] = dict(ms_per_step=m["ms"], value=m["value"], unit="rays/s", steps=steps, warmup=warm, metric=wl.metric(),
                                      workload=wl.describe(), n_gpus=ctx.world, roofline=wl.roofline(m, full=False),
-                                     kernel_ms_per_step=m["timing"].get("per_step_ms"), seconds=None)
+                                     kernel_ms_per_step=m["timing"].get("per_step_ms"), host_issue_ms=m["host_issue_ms"],
+                                     sum_timed_kernel_ms=m["sum_timed_kernel_ms"],
+                                     captured=(bool((wl.renderer.__dict__.get("_fwd_graph") or {}).get("graph")) if wl.mode == "forward" else None),
+                                     seconds=None)
         except Exception as e:      # an extra must never cost the headline line
             ok = False
             partial[name] = dict(error="%s: %s" % (type(e).__name__, str(e)[:500]))
@@ -615,6 +651,9 @@ def main():
                    ranks_seen_by_collective=proof["ranks_seen_by_collective"] if proof else None,
                    allreduce_ms=proof["allreduce_ms"] if proof else None,
                    collective_proof=({k: v for k, v in proof.items() if k != "per_rank_seconds"} if proof else None),
+                   host_issue_ms=m["host_issue_ms"], sum_timed_kernel_ms=m["sum_timed_kernel_ms"],
+                   host_note="host_issue_ms: CPU time to enqueue one step into an empty queue (median of 5); sum_timed_kernel_ms: the MLP chain / "
+                             "query / weight-gradient launches of one step (HIP events; the two front-end chains of a training step overlap)",
                    roofline=wl.roofline(m), kernel_ms_per_step=timing.get("per_step_ms"), kernel_symbols=timing.get("symbols"),
                    kernel_launch_groups=timing.get("launch_groups"), cpu_baseline=None, extras=None)
     headline_is_default = args.config == 2 and mode == "train" and not args.split_precision and not args.rays
@@ -647,6 +686,9 @@ def main():
     timer.start()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
+        # the extras follow ~30 s of 16-thread CPU work: let the host settle and keep torch's intra-op pool out of the launch thread's way
+        torch.set_num_threads(1)
+        time.sleep(1.0)
     if want_extras:
         run_extras(ctx, args, extras)
     timer.cancel()

@@ -59,6 +59,10 @@ constexpr int weff_layer_off(int net, int l) {
 constexpr int weff_w_off(int net, int l) { return weff_layer_off(net, l); }
 constexpr int weff_b_off(int net, int l) { return weff_layer_off(net, l) + LAYER_N[net][l] * LAYER_K[net][l]; }
 constexpr int WEFF_FLOATS = weff_layer_off(NETS - 1, LAYERS - 1) + LAYER_N[NETS - 1][LAYERS - 1] * (LAYER_K[NETS - 1][LAYERS - 1] + 1);
+// The chain kernels request a layer's bias as one value per output COLUMN OF THE 256-WIDE TILE (query.hip bias2 and friends): for the
+// one layer with fewer outputs (deform layer 3: 204) the lanes of columns 204..255 read past its bias vector into the next layer's
+// weights.  The values are never used (the skip copy overwrites those columns); the reads must stay inside the buffer.
+static_assert(weff_b_off(NET_D, 3) + HID <= WEFF_FLOATS, "bias reads of a 256-wide tile must stay inside the effective-weight buffer");
 
 // ---- packed MFMA B-operand segments --------------------------------------------------------------
 // One segment = one GEMM operand B[k][n] (k = contraction index, n = output column) stored as

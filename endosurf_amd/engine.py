@@ -120,12 +120,16 @@ class Engine:
         return self._ones1
 
     def uniform(self, n: int, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """n uniform draws in [0, 1) in ONE launch (Philox4x32-10 keyed by torch's seed; one subsequence per call, plus -- inside a
-        captured step -- the device-resident step counter, so that replays draw new numbers)."""
+        """n uniform draws in [0, 1) in ONE launch (Philox4x32-10 keyed by torch's seed).  Eager steps: subsequence = this engine's call
+        index.  Graph-mode steps: subsequence = 2^63 + the device-resident step counter, so that replays draw new numbers."""
         out = self.empty(int(n))
         seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        sub = self._rng_calls
-        if not torch.cuda.is_current_stream_capturing():
+        if step_dev is not None:
+            # graph-mode steps (the two eager warm-up calls and every replay) draw from subsequences 2^63 + step counter: a space
+            # disjoint from the eager steps' call index below, so that mixing train_step and train_step_graph never repeats a stream
+            sub = 1 << 63
+        else:
+            sub = self._rng_calls
             self._rng_calls += 1
         check(self.lib.es_uniform(ptr(out), int(n), seed, sub, ptr(step_dev) if step_dev is not None else None, self.st()), "es_uniform")
         return out
@@ -460,6 +464,7 @@ Engine.point_backward = _point_backward
 
 
 def _timing_enable(self, on: bool):
+    self._timing_on = bool(on)          # (events cannot be recorded inside a captured graph: the renderer's captured forward stands down)
     check(self.lib.es_timing_enable(int(on)), "es_timing_enable")
 
 

@@ -430,7 +430,8 @@ class Trainer:
         on two streams -- captured ONCE per batch shape in a hipGraph (torch.cuda.CUDAGraph) and replayed.  Everything that changes from
         step to step lives in device memory: the batch (copied into static buffers), the step counters from which the first launch of the
         step computes the learning rate, Adam's bias corrections and the cos-anneal ratio (es_train_schedule: the reference's
-        update_learning_rate / get_cos_anneal_ratio on the device), the random draws (torch's graph-safe generator).  The first two calls
+        update_learning_rate / get_cos_anneal_ratio on the device), the random draws (es_uniform: Philox keyed by torch.initial_seed(), the
+        subsequence taken from the device-resident step counter).  The first two calls
         run eagerly (lazy initialisation; they are ordinary training steps), the third captures.  Under data parallelism the graph ends
         with the flat gradient; the all-reduce and the Adam launch follow it eagerly.  Returns the loss (a static device tensor)."""
         with torch.cuda.device(self.renderer.device):
@@ -509,6 +510,11 @@ class Trainer:
                     g["loss"], g["flat"] = body()
                 opt.step_count = count                         # capturing launches nothing: the step count advances with the replays
                 g["graph"] = graph
+                # The step arena is the one buffer of a captured step that does NOT live in the graph's private pool: its address is baked
+                # into the graph's memset and into every launch that uses a slice of it.  The graph keeps it alive, so an eager step with a
+                # larger batch in between (which makes the engine allocate a new, larger arena) cannot hand the old block back to the
+                # caching allocator while replays still write into it.
+                g["arena"] = r.engine._arena
             g["graph"].replay()
             if self.data_parallel:
                 finish(g["flat"])                              # (opt.step advances the count itself)

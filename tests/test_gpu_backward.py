@@ -40,6 +40,11 @@ def _dump(name, rows):
         json.dump(rows, f, indent=1)
 
 
+# (per-tensor bound, median bound) on the relative L2 error of a parameter-gradient tensor of test_point_backward; "split": the same test
+# through the split-precision chain kernels (tests/test_gpu_train_x3.py), at that family's own measured level
+POINT_TOL = {"fp32": (5e-4, 1e-4), "split": (5e-4, 1e-4)}
+
+
 @pytest.mark.parametrize("mode,use_deform,color", [("init", True, True), ("trained", True, True), ("trained", False, True),
                                                    ("trained", True, False)])
 def test_point_backward(mode, use_deform, color):
@@ -73,11 +78,16 @@ def test_point_backward(mode, use_deform, color):
     ref.backward()
     assert abs(float(loss) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
     rows = _grad_table(r, params)
-    _dump(f"point_{mode}_{int(use_deform)}_{int(color)}", rows)
-    bad = {k: v for k, v in rows.items() if v[0] > 2e-2 and v[1] > 1e-7 and k != "deviation_network.variance"}
+    split = bool(r.engine.split_precision)
+    _dump(f"point_{mode}_{int(use_deform)}_{int(color)}" + ("_split" if split else ""), rows)
+    # At fixed points the kernels agree with autograd on the fp64 oracle to 2.3e-6 ... 2.3e-5 relative L2 per parameter tensor
+    # (82 tensors x 4 cases, gpurun_out/grad_point_*.json of round 4).  The gate sits at max(20 x measured, 5e-4) = 5e-4 per tensor and
+    # 1e-4 for the median (round 5; it was 2e-2 / 2e-3, which a 1 % defect in one small tensor would have passed).  No tensor needs more.
+    per_tensor, median = POINT_TOL["split" if split else "fp32"]
+    bad = {k: v for k, v in rows.items() if v[0] > per_tensor and v[1] > 1e-7 and k != "deviation_network.variance"}
     assert not bad, bad
     med = float(np.median([v[0] for k, v in rows.items() if v[1] > 1e-7]))
-    assert med < 2e-3, med
+    assert med < median, med
 
 
 def _render_scalar(ret, c, dt, dev):
