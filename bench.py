@@ -295,6 +295,15 @@ class Ctx:
         return [float(o.item()) for o in out]
 
 
+    def gather_obj(self, x):
+        import torch
+        if not self.dist_on:
+            return [x]
+        out = [None] * self.world
+        torch.distributed.all_gather_object(out, x)
+        return out
+
+
 class Workload:
     """One BASELINE.json configuration on this rank: renderer + trainer + resident synthetic batches, ``step(i)`` = one pass of the hot
     path (a full training step, a forward, or one 640x512 frame)."""
@@ -311,6 +320,7 @@ class Workload:
             cfg["rays"] = rays
         self.ctx, self.cfg, self.mode, self.config_id, self.split, self.chunk, self.rays_override = ctx, cfg, mode, config_id, bool(split), chunk, rays
         self.graph, self.frame_graph = bool(graph) and mode == "train", frame_graph
+        self.graph_probe = False          # set by main() for the headline workload of an N > 1 run (or --graph-probe)
         torch.manual_seed(0)
         self.renderer = EndoSurfRenderer(render_cfg(cfg), dict(NET_CFG, use_deform=cfg["use_deform"]), device=ctx.dev)
         if split:
@@ -377,6 +387,28 @@ class Workload:
             torch.cuda.synchronize()
         return sorted(ts)[len(ts) // 2]
 
+    def probe_graph(self, first, steps, dt_eager, dt_eager_local, issue_ms):
+        """-> dict(ms_per_step (max over ranks), per-rank gpu_idle_ms estimate, the fallback decision); see measure()."""
+        ctx = self.ctx
+        out = dict(steps=steps)
+        try:
+            self.use_graph = True
+            for i in range(4):          # two eager initialisation steps, the capture + first replay, one more replay
+                self.step(first + i)
+            dtg, dtg_local = self.timed(first + 4, steps)
+        except Exception as e:          # (a failed capture must not cost the eager line)
+            self.use_graph = False
+            return dict(error="%s: %s" % (type(e).__name__, str(e)[:300]), use_graph=False)
+        self.use_graph = False
+        eager_ms, graph_ms = dt_eager / steps * 1e3, dtg / steps * 1e3
+        issue_max = ctx.max_over_ranks(issue_ms)
+        host_bound = issue_max > 0.8 * eager_ms
+        use = bool(host_bound and graph_ms < eager_ms)
+        out.update(ms_per_step=graph_ms, eager_ms_per_step=eager_ms, host_issue_ms_max=issue_max, host_bound=bool(host_bound), use_graph=use,
+                   gpu_idle_ms=max(0.0, (dt_eager_local - dtg_local) / steps * 1e3), dt=dtg, dt_local=dtg_local,
+                   rule="headline = the replayed step iff rank-max host_issue_ms > 0.8 x eager ms_per_step and the replayed step is faster")
+        return out
+
     def measure(self, warmup, steps, timing_steps=3, early_exit_extra=True):
         """warm-up, the timed region, (train) the same step with the marching early exit, then a few instrumented steps."""
         eng, mode = self.eng, self.mode
@@ -401,6 +433,16 @@ class Workload:
             eng.march_block = 0
         issue_ms = self.host_issue_ms(nxt) if mode != "frame" else None
         nxt += 5
+        # N > 1 (cold-run kit): the same step replayed from the whole-step hipGraph -- a step that needs NO host work between its first
+        # and its last launch.  Its time is this rank's GPU-bound step time (on one GPU it is within 1 % of the eager step), so
+        # eager - graph is the time per step the GPU spent waiting for this rank's host; and when the host is the limiter (rank-max
+        # host_issue_ms > 0.8 x ms_per_step) and the replayed step is faster, the replayed step IS the headline (config says so).
+        probe = None
+        if mode == "train" and self.graph_probe and not self.use_graph:
+            probe = self.probe_graph(nxt, steps, dt, dt_local, issue_ms)
+            nxt += 4 + steps
+            if probe.get("use_graph"):
+                dt, dt_local = probe["dt"], probe["dt_local"]
         self.use_graph = False         # (events cannot be recorded inside a captured graph: the per-kernel timers run on eager steps)
         rec = self.ctx.rank == 0       # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 records
         if mode == "frame":
@@ -420,7 +462,7 @@ class Workload:
         per = timing.get("per_step_ms")
         return dict(dt=dt, dt_local=dt_local, steps=steps, warmup=warmup, ms=dt / steps * 1e3, value=self.rays_per_step_job * steps / dt,
                     with_early_exit=extra, timing=timing, flops_per_step=flops_per_step, next_step=nxt + 64 + timing_steps,
-                    host_issue_ms=issue_ms, sum_timed_kernel_ms=(sum(per.values()) if per and mode != "frame" else None))
+                    host_issue_ms=issue_ms, sum_timed_kernel_ms=(sum(per.values()) if per and mode != "frame" else None), graph_probe=probe)
 
     def roofline(self, m, full=True):
         timing, ms, flops_per_step = m["timing"], m["ms"], m["flops_per_step"]
@@ -510,8 +552,33 @@ def collective_proof(ctx, wl, dt_local):
     b.record()
     torch.cuda.synchronize()
     ar_ms = ctx.max_over_ranks(a.elapsed_time(b) / n)
+    # the same collective INSIDE training steps: HIP events around it on the launch stream.  In a step it is issued behind the last launch
+    # of the backward (es_weightnorm_backward writes the bucket last) and the Adam launch consumes its result, so all of it is exposed;
+    # what the events add to the back-to-back figure is the skew between the ranks at that point of the step.
+    in_step = None
+    if wl.mode == "train" and not wl.use_graph:
+        wl.trainer.allreduce_events = []
+        for i in range(4):
+            wl.step(10_000 + i)
+        torch.cuda.synchronize()
+        ts = [x.elapsed_time(y) for x, y in wl.trainer.allreduce_events]
+        wl.trainer.allreduce_events = None
+        if ts:
+            in_step = ctx.max_over_ranks(sorted(ts)[len(ts) // 2])
+    # the replicas after all the steps above: every rank's flat parameter buffer against rank 0's, bit for bit (the summed bucket and the
+    # update are the same on every rank, so any difference is a bug)
+    mine = wl.renderer.model._flat.detach()
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    diff = (mine != ref).sum().to(torch.float64).reshape(1)
+    dist.all_reduce(diff)
     return dict(ranks_seen_by_collective=int(round(float(ones.item()))), bucket_bytes=4 * wl.eng.n_param,
-                allreduce_ms=ar_ms, allreduce_note="mean of %d back-to-back all-reduces of the 6.6 MB flat gradient bucket, HIP events on the "
+                replicas_bit_identical=bool(float(diff.item()) == 0.0), replica_words_differing=int(diff.item()),
+                allreduce_ms=ar_ms, allreduce_in_step_ms=in_step, allreduce_exposed_ms=in_step, allreduce_hidden_ms=0.0 if in_step is not None else None,
+                allreduce_overlap_note="exposed = the collective as the step's launch stream sees it (median of 4 steps, MAX over ranks): the bucket is "
+                "complete only behind the last backward launch and Adam needs all of it, so nothing of a step can hide it (hidden = 0); a "
+                "per-network bucket pipeline is described in DESIGN 5 and not built",
+                allreduce_note="mean of %d back-to-back all-reduces of the 6.6 MB flat gradient bucket, HIP events on the "
                 "launch stream, MAX over ranks (in a step it is issued once, after the last weight-gradient launch)" % n,
                 per_rank_seconds=per_rank)
 
@@ -586,6 +653,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="train mode: the whole training step captured once in a hipGraph and replayed (Trainer.train_step_graph); the "
                          "per-kernel timers then run on a few eager steps after the timed region")
+    ap.add_argument("--graph-probe", action="store_true",
+                    help="also time the step replayed from the whole-step hipGraph and apply the host-bound fallback rule (always on at N > 1)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to disjoint host-core sets")
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
@@ -619,12 +689,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = Ctx(dev, rank, world, dist_on, force_dist, backend, args.schedule)
+    # cold-run kit: every local rank on its own host cores (within the mask this process was given)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    affinity = (parallel.pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), local_world) if world > 1 and not args.no_pin
+                else dict(pinned=False, reason="one rank" if world == 1 else "--no-pin"))
 
     # ---- headline ---------------------------------------------------------------------------------------------------------------
     wl = Workload(ctx, args.config, mode=args.mode, split=args.split_precision, rays=args.rays, chunk=args.chunk, graph=args.graph,
                   frame_graph=not args.no_graph)
+    wl.graph_probe = (world > 1 or args.graph_probe) and wl.mode == "train" and not args.graph and not args.split_precision
     m = wl.measure(args.warmup, args.steps, early_exit_extra=not args.headline_only)
     proof = collective_proof(ctx, wl, m["dt_local"]) if dist_on else None
+    probe = m.get("graph_probe")
+    # per-rank diagnostics of a cold N > 1 run, gathered once (every rank contributes; rank 0 prints)
+    per_rank = ctx.gather_obj(dict(rank=rank, host_issue_ms=m["host_issue_ms"], affinity=affinity,
+                                   gpu_idle_ms=(probe or {}).get("gpu_idle_ms"), ms_per_step=m["dt_local"] / args.steps * 1e3))
     cfg, mode, timing = wl.cfg, wl.mode, m["timing"]
     out = None
     if rank == 0:
@@ -637,7 +716,8 @@ def main():
                    data="synthetic",
                    config=dict(workload=wl.describe(),
                                baseline_config=args.config, use_deform=cfg["use_deform"], split_precision=bool(args.split_precision),
-                               whole_step_hipgraph=bool(args.graph) and mode == "train",
+                               whole_step_hipgraph=(bool(args.graph) or bool((probe or {}).get("use_graph"))) and mode == "train",
+                               graph_fallback=((probe or {}).get("rule") if (probe or {}).get("use_graph") else None),
                                ray_marching="all 128 proposals of every ray (data independent, as the reference)" if mode == "train" else None,
                                with_early_exit=m["with_early_exit"], rays_per_gpu=wl.n_rays if mode != "frame" else None,
                                rays_per_step_whole_job=wl.rays_per_step_job,
@@ -652,6 +732,14 @@ def main():
                    allreduce_ms=proof["allreduce_ms"] if proof else None,
                    collective_proof=({k: v for k, v in proof.items() if k != "per_rank_seconds"} if proof else None),
                    host_issue_ms=m["host_issue_ms"], sum_timed_kernel_ms=m["sum_timed_kernel_ms"],
+                   host_issue_ms_min=min(r["host_issue_ms"] for r in per_rank) if per_rank[0]["host_issue_ms"] is not None else None,
+                   host_issue_ms_max=max(r["host_issue_ms"] for r in per_rank) if per_rank[0]["host_issue_ms"] is not None else None,
+                   gpu_idle_ms_min=min(r["gpu_idle_ms"] for r in per_rank) if per_rank[0]["gpu_idle_ms"] is not None else None,
+                   gpu_idle_ms_max=max(r["gpu_idle_ms"] for r in per_rank) if per_rank[0]["gpu_idle_ms"] is not None else None,
+                   gpu_idle_note="per rank: eager ms_per_step - ms_per_step of the same step replayed from the whole-step hipGraph (which needs no "
+                                 "host work between its launches): the time per step the GPU waited for that rank's host",
+                   graph_probe=({k: v for k, v in probe.items() if k not in ("dt", "dt_local", "gpu_idle_ms")} if probe else None),
+                   per_rank=per_rank,
                    host_note="host_issue_ms: CPU time to enqueue one step into an empty queue (median of 5); sum_timed_kernel_ms: the MLP chain / "
                              "query / weight-gradient launches of one step (HIP events; the two front-end chains of a training step overlap)",
                    roofline=wl.roofline(m), kernel_ms_per_step=timing.get("per_step_ms"), kernel_symbols=timing.get("symbols"),

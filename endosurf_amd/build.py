@@ -73,4 +73,4 @@ def build(force: bool = False, verbose: bool = True, extra=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
+    build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith(("-R", "-save", "-D"))])

@@ -175,6 +175,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 }
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
+int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
+                const int* ray_done, bool half, int dbg);
 
 // tile_points: 0 = chosen by the batch size (<= 9 216 points: the 16-point tiles of query16.hip -- the up-sampling queries of 1 024 rays and
 // the secant iterations are latency-bound on their own; <= 16 384: 32-point tiles, fewer than one 64-point tile per CU otherwise; above: 64),
@@ -192,6 +194,11 @@ int query_sdf(const PointSrc& src, const float* packed, const float* weff, float
     if (tp == 16 && !(ld_out == 0 && ray_done == nullptr)) tp = 32;      // (the 16-point kernel writes flat outputs only)
     if (src.M > 0 && tp == 16)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
+#ifdef ES_DEV_SWITCHES      // dev builds only: A/B of the transposed formulation (query_t.hip): ES_QT=1 both tile heights, 2 = 64-point tiles only
+    static const int qt_env = getenv("ES_QT") ? atoi(getenv("ES_QT")) : 0;
+    if (qt_env == 1 || qt_env == 3 || (qt_env == 2 && tp == 64)) return query_sdf_t(src, packed, weff, sdf_out, use_deform, st, ld_out, ray_done, tp == 32, qt_env == 3);
+    if (qt_env >= 100) return query_sdf_t(src, packed, weff, sdf_out, use_deform, st, ld_out, ray_done, tp == 32, qt_env - 100);
+#endif
     static DeviceOnce attr_done;
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;

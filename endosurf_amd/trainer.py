@@ -394,6 +394,7 @@ class Trainer:
         # data parallel: all-reduce the loss normalisers before the backward, so that N ranks x B rays train exactly like one rank with
         # N x B rays (default: standard DDP semantics, per-rank ratios averaged)
         self.exact_denominators = bool(exact_denominators)
+        self.allreduce_events = None        # a list: train_step appends a HIP-event pair around its gradient all-reduce
         if self.exact_denominators:
             if schedule != "fused":
                 raise ValueError("exact_denominators needs the fused schedule")
@@ -546,7 +547,13 @@ class Trainer:
             if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update
                 from .parallel import allreduce_flat
                 g = self.optimizer.flat_grad(include_variance=True)
+                ev = self.allreduce_events
+                if ev is not None:      # measurement: HIP events around the step's one data-path collective (bench.py collective_proof)
+                    ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    ev[-1][0].record()
                 world = allreduce_flat(g, group=self.group, force=self.force_collective)
+                if ev is not None:
+                    ev[-1][1].record()
                 self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
             else:
                 self.optimizer.step()

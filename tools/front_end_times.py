@@ -141,3 +141,59 @@ out["query16_8192_points_ms"] = timed(lambda: eng.query_sdf(eng.points(x=xm[:819
 out["query16_1024_points_ms"] = timed(lambda: eng.query_sdf(eng.points(x=x1, t=t1), weff, packed, True))
 print(json.dumps(out, indent=1))
 json.dump(out, open("gpurun_out/front_end_times.json", "w"), indent=1)
+
+
+# ---- round 5: the coarse 32 768-point query INSIDE the marching launch (one 163 840-point grid = 2 560 tiles = five
+# full rounds of the chip's 512 workgroup slots instead of four rounds + a 512-tile launch racing the secant chain), leaving only
+# 3 x (up-sample + 8 192-point query + merge) + the last up-sample on the sampling stream next to the secant chain.  Emulated with the
+# kernels that exist: ONE query launch over 160 depths per ray (results meaningless, the timing is that of the fused grid), then the two
+# chains side by side without the coarse query.
+z160 = eng.empty(N, 160)
+eng.ray_setup(rays, None, 160, 0.0, 1, z160)
+sdf_c32 = eng.query_sdf(eng.points(rays=rays, z=zc, n_per_ray=n0, ldz=S), weff, packed, True).view(N, n0)
+
+
+sdf_b2 = eng.empty(N, S)
+
+
+def fused_grid():
+    eng.query_sdf(eng.points(rays=rays, z=z160, n_per_ray=160, ldz=160), weff, packed, True)
+
+
+def rest_of_sampling():
+    sd, ld = sdf_c32, n0
+    for i in range(4):
+        _lib.check(eng.lib.es_upsample_step(_lib.ptr(rays), _lib.ptr(zc), S, _lib.ptr(sd), ld, N, n0 + i * n_imp, n_imp, float(64 * 2 ** i),
+                                            _lib.ptr(z_new), _lib.ptr(zn), S, _lib.ptr(src), st()), "up")
+        if i < 3:
+            f = eng.query_sdf(eng.points(rays=rays, z=z_new, n_per_ray=n_imp, ldz=n_imp), weff, packed, True)
+            dst = sdf_a if sd.data_ptr() != sdf_a.data_ptr() else sdf_b2
+            _lib.check(eng.lib.es_merge_sdf(_lib.ptr(sd), ld, _lib.ptr(f), n_imp, _lib.ptr(src), S, N, n0 + i * n_imp, _lib.ptr(dst), st()), "merge")
+            sd, ld = dst, S
+
+
+def racing_without_coarse():
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        rest_of_sampling()
+    r._march_refine(ms)
+    main.wait_stream(side)
+
+
+def fused_front_end():
+    fused_grid()
+    racing_without_coarse()
+
+
+def current_front_end():
+    r._march_begin(rays)
+    both()
+
+
+out["fused_grid_163840_points_ms"] = timed(fused_grid)
+out["sampling_chain_without_coarse_query_alone_ms"] = timed(rest_of_sampling)
+out["racing_section_without_coarse_query_ms"] = timed(racing_without_coarse)
+out["fused_front_end_emulated_ms"] = timed(fused_front_end)
+out["current_front_end_ms"] = timed(current_front_end)
+print(json.dumps({k: v for k, v in out.items() if "fused" in k or "without" in k or "current" in k}, indent=1))
+json.dump(out, open("gpurun_out/front_end_times.json", "w"), indent=1)
