@@ -175,8 +175,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 }
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
+#ifdef ES_DEV_SWITCHES      // query_t.hip: the transposed formulation, dev builds only
 int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
                 const int* ray_done, bool half, int dbg);
+#endif
 
 // tile_points: 0 = chosen by the batch size (<= 9 216 points: the 16-point tiles of query16.hip -- the up-sampling queries of 1 024 rays and
 // the secant iterations are latency-bound on their own; <= 16 384: 32-point tiles, fewer than one 64-point tile per CU otherwise; above: 64),

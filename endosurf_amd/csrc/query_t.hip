@@ -19,6 +19,13 @@
 // bias of its own 64 features of the current layer in the 4-float padding of the encoding tile's rows (256 floats = one layer), reads
 // it back as 8 broadcast ds_read_b128 and stages the next layer's values behind its own epilogue (no barrier: a wave only ever touches
 // its own 64 entries).  LDS: 64 x 260 + 64 x 60 floats = exactly 80 KiB, two workgroups per CU as before.
+// STATUS (round 5): measured and NOT kept.  Bit-identical to query.hip on every shape tried, and the same speed to +-0.3 % (1.893 vs 1.891 ms
+// on the 131 072-point launch): the LDS instruction count is not what bounds these kernels (DEAD_ENDS.md, profiles/r05_ab_query_transposed.txt).
+// This translation unit is compiled only into dev builds (python -m endosurf_amd.build -DES_DEV_SWITCHES), where ES_QT selects it and
+// its timing-experiment instantiations (tools/qt_ab.py); the product library does not contain it.
+#ifdef ES_DEV_SWITCHES
+#include <cstdlib>
+
 #include "chain_common.h"
 #include "launch.h"
 #include "tabs.h"
@@ -197,6 +204,7 @@ __device__ __forceinline__ void smalln_partial_t(const float* Xt, const float* _
 }
 
 #define QT_SYNC() do { if (!(DBG & 16)) __syncthreads(); } while (0)
+__device__ unsigned qt_cu_arrivals[4096];      // dev experiment (DBG & 32): arrivals per CU of the current launch (host clears it)
 template <bool DEFORM, bool HALF, int DBG = 0>      // DBG: dev builds only (timing experiments; results are garbage): 2 = no activation math,
                                                     // 4 = weights loaded for the first groups of a segment only, 8 = activations likewise, 16 = no barriers
 __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf_t(PointSrc src, Tabs tb, const float4* __restrict__ packed,
@@ -216,6 +224,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf_t(PointSrc src, Tabs 
         bool all_done = true;
         for (int r = r_first; r <= r_last; ++r) all_done = all_done && ray_done[r] != 0;
         if (all_done) return;       // workgroup-uniform
+    }
+    if (DBG & 32) {      // stagger: the SECOND workgroup to arrive on a CU waits ``dbg`` x 1024 cycles before it starts
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned cu = ((((xcc & 0xf) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xf)) & 4095;
+        unsigned* arrival = reinterpret_cast<unsigned*>(lds);      // (no static LDS: it would shift the dynamic base off its 16-byte alignment)
+        if (tid == 0) *arrival = atomicAdd(&qt_cu_arrivals[cu], 1u);
+        __syncthreads();
+        const unsigned arr = *arrival;
+        __syncthreads();
+        if (arr == 1) {
+            const long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (long long)dbg * 1024) __builtin_amdgcn_s_sleep(32);
+        }
     }
     const int lo = lane & 31, hi = lane >> 5;
     auto X = [&](int row, int c) -> float& { return mainT[row * LDM + HID + c]; };
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf_t(PointSrc src, Tabs 
             f32x16 acc[2][PTC];
             acc_zero(acc);
             if (l < 7) bn = weff[tb.boff[NET_D * LAYERS + l + 1] + bias_feat];
-            gemm_seg_t<32, PTC, LDM, DBG>(acc, mainT, packed + tb.segoff[DF0 + l], 2 * wave, lane, dbg);
+            gemm_seg_t<32, PTC, LDM, DBG, (DBG & 64) ? 4 : 2>(acc, mainT, packed + tb.segoff[DF0 + l], 2 * wave, lane, dbg);
             const Bias8 bias = load_bias8(bias_row);
             QT_SYNC();
             if (l == 3 && wave == 3) {      // (wave-uniform) IDR skip: next input = [h(204) | enc(52)] (1/sqrt2 folded into W4)
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf_t(PointSrc src, Tabs 
         acc_zero(acc);
         if (l < 7) bn = weff[tb.boff[NET_S * LAYERS + l + 1] + bias_feat];
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
-        gemm_seg_t<32, PTC, LDM, DBG>(acc, mainT, packed + tb.segoff[seg], 2 * wave, lane, dbg);
+        gemm_seg_t<32, PTC, LDM, DBG, (DBG & 64) ? 4 : 2>(acc, mainT, packed + tb.segoff[seg], 2 * wave, lane, dbg);
         if (l == 4) gemm_seg_t<5, PTC, LDA, DBG>(acc, aux, packed + tb.segoff[SF4A], 2 * wave, lane, dbg);   // NeRF skip: + enc part
         const Bias8 bias = load_bias8(bias_row);
         QT_SYNC();
@@ -371,6 +394,22 @@ int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, flo
             allow_big_lds(k_query_sdf_t<true, false, 30>, QT_LDS_BYTES); allow_big_lds(k_query_sdf_t<true, false, 12>, QT_LDS_BYTES);
             attr = true;
         }
+        if (dbg == 64) {
+            static bool a64 = false;
+            if (!a64) { allow_big_lds(k_query_sdf_t<true, false, 64>, QT_LDS_BYTES); a64 = true; }
+            hipLaunchKernelGGL((k_query_sdf_t<true, false, 64>), grid, block, QT_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done, 0);
+            return hip_last("query_sdf_t");
+        }
+        if (dbg == 32) {
+            static bool a32 = false;
+            if (!a32) { allow_big_lds(k_query_sdf_t<true, false, 32>, QT_LDS_BYTES); a32 = true; }
+            static const int delay = getenv("ES_QT_DELAY") ? atoi(getenv("ES_QT_DELAY")) : 0;
+            void* cnt = nullptr;
+            hipGetSymbolAddress(&cnt, HIP_SYMBOL(qt_cu_arrivals));
+            hipMemsetAsync(cnt, 0, sizeof(unsigned) * 4096, st);
+            hipLaunchKernelGGL((k_query_sdf_t<true, false, 32>), grid, block, QT_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done, delay);
+            return hip_last("query_sdf_t");
+        }
         switch (dbg) {
             case 2: hipLaunchKernelGGL((k_query_sdf_t<true, false, 2>), grid, block, QT_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done, 0); break;
             case 4: hipLaunchKernelGGL((k_query_sdf_t<true, false, 4>), grid, block, QT_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done, 0); break;
@@ -393,3 +432,5 @@ int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, flo
 }
 
 }  // namespace es
+
+#endif  // ES_DEV_SWITCHES

@@ -148,8 +148,7 @@ json.dump(out, open("gpurun_out/front_end_times.json", "w"), indent=1)
 # 3 x (up-sample + 8 192-point query + merge) + the last up-sample on the sampling stream next to the secant chain.  Emulated with the
 # kernels that exist: ONE query launch over 160 depths per ray (results meaningless, the timing is that of the fused grid), then the two
 # chains side by side without the coarse query.
-z160 = eng.empty(N, 160)
-eng.ray_setup(rays, None, 160, 0.0, 1, z160)
+z160 = (torch.rand(N, 160, device=dev) * 2.0).contiguous()
 sdf_c32 = eng.query_sdf(eng.points(rays=rays, z=zc, n_per_ray=n0, ldz=S), weff, packed, True).view(N, n0)
 
 
@@ -160,16 +159,24 @@ def fused_grid():
     eng.query_sdf(eng.points(rays=rays, z=z160, n_per_ray=160, ldz=160), weff, packed, True)
 
 
+zc0 = zc.clone()
+
+
 def rest_of_sampling():
-    sd, ld = sdf_c32, n0
+    """engine.sample_z without its ray set-up and coarse query (they ride in the fused grid)."""
+    za, zb = zc, zn
+    za.copy_(zc0)
+    sd, ld, n = sdf_c32, n0, n0
     for i in range(4):
-        _lib.check(eng.lib.es_upsample_step(_lib.ptr(rays), _lib.ptr(zc), S, _lib.ptr(sd), ld, N, n0 + i * n_imp, n_imp, float(64 * 2 ** i),
-                                            _lib.ptr(z_new), _lib.ptr(zn), S, _lib.ptr(src), st()), "up")
+        _lib.check(eng.lib.es_upsample_step(_lib.ptr(rays), _lib.ptr(za), S, _lib.ptr(sd), ld, N, n, n_imp, float(64 * 2 ** i),
+                                            _lib.ptr(z_new), _lib.ptr(zb), S, _lib.ptr(src), st()), "up")
         if i < 3:
             f = eng.query_sdf(eng.points(rays=rays, z=z_new, n_per_ray=n_imp, ldz=n_imp), weff, packed, True)
             dst = sdf_a if sd.data_ptr() != sdf_a.data_ptr() else sdf_b2
-            _lib.check(eng.lib.es_merge_sdf(_lib.ptr(sd), ld, _lib.ptr(f), n_imp, _lib.ptr(src), S, N, n0 + i * n_imp, _lib.ptr(dst), st()), "merge")
+            _lib.check(eng.lib.es_merge_sdf(_lib.ptr(sd), ld, _lib.ptr(f), n_imp, _lib.ptr(src), S, N, n, _lib.ptr(dst), st()), "merge")
             sd, ld = dst, S
+        za, zb = zb, za
+        n += n_imp
 
 
 def racing_without_coarse():
