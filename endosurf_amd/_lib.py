@@ -79,6 +79,7 @@ PROTOTYPES = {
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_color_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _P]),
+    "es_point_vjp": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
     "es_point_forward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P]),
     "es_gemm_atb": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "es_point_backward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -109,10 +110,10 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
-WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
+WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB, WS_CURV, WS_XCBAR = range(9)
 
 _lib = None
 

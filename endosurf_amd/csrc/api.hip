@@ -23,6 +23,7 @@ int variance_terms(const float* variance, const float* d_invs_acc, float* s_val,
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st,
                   const void* packed_x3 = nullptr);
 int color_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, hipStream_t st);
+int point_vjp(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st, const void* packed_x3 = nullptr);
 int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
@@ -241,6 +242,13 @@ int es_point_forward(const es_points* pts, const float* packed, const float* wef
     ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     return point_forward(to_src(pts), packed, weff, ws, flags, m_color, (hipStream_t)stream);
+}
+int es_point_vjp(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
+    ES_REQUIRE(flags & ES_PF_DEFORM, "es_point_vjp is the reverse sweep of the deformation network (ES_PF_DEFORM)");
+    ES_REQUIRE(!(flags & ES_PF_X3_CHAIN), "the workspace must come from es_point_forward (fp32 family: its ReLU mask words)");
+    return point_vjp(to_src(pts), packed, weff, ws, flags, (hipStream_t)stream);
 }
 int es_color_forward(const es_points* pts, const float* packed, const float* weff, float* ws, void* stream) {
     if (int e = check_src(pts)) return e;

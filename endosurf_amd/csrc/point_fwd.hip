@@ -138,6 +138,20 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
 }
 
 
+// The VJP sweep of the deformation network on its own, for the covector the caller has written to WS_GC of a workspace that a forward
+// of the SAME points has filled (the sweep reads that forward's ReLU mask words): WS_GO = J^T c, WS_CURV = the encoding-curvature sums
+// against the same adjoint.  Nothing is saved (PF_SAVE is ignored: the forward's saved VJP adjoints stay as they are).
+int point_vjp(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st) {
+    if (src.M <= 0) return ST_OK;
+    FwdArgs a;
+    a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
+    a.L = ws_layout(src.M, flags); a.flags = flags & ~PF_SAVE;
+    a.M_color = 0;
+    ScopedTimer tm(KID_DEFORM_VJP, src.M, st);
+    if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, a.L.Mp / TM, 0, st)) return e;
+    return hip_last("point_vjp");
+}
+
 // ColorNetwork.forward(x, n, d, geo_feat) (reference endosurf.py:828-842) on explicit inputs: the caller has written x -> WS_XC,
 // n -> WS_GC, geo_feat -> WS_FEAT of a (PF_COLOR, no deformation) workspace and passes d as the point source's view directions; only
 // the colour body runs, with the direction taken as given (EndoSurfNet.forward normalises J d before it calls the colour network,

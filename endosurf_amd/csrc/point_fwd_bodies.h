@@ -245,14 +245,18 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
         float x[3], t, d[3];
         load_point(a.src, row0 + row, x, t, d);
         float g = g8[j * 64 + row] + aux[swz(j, row)];
+        float c2 = 0.f;      // the encoding's curvature against the same adjoint (WS_CURV: second derivative of the query w.r.t. the point)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const float f = (float)(1 << i);
             float s, co;
             sincosf(x[j] * f, &s, &co);
-            g += f * (aux[swz(enc_index(3, i, 0, j), row)] * co - aux[swz(enc_index(3, i, 1, j), row)] * s);
+            const float as = aux[swz(enc_index(3, i, 0, j), row)], ac = aux[swz(enc_index(3, i, 1, j), row)];
+            g += f * (as * co - ac * s);
+            c2 += (f * f) * (as * s + ac * co);
         }
         wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
+        wsb(a, WS_CURV)[(grow0 + row) * 3 + j] = c2;
     }
 }
 

@@ -400,7 +400,7 @@ class Engine:
 class PointCtx:
     """Workspace of one fused point evaluation + typed views of its outputs."""
     _OUT = {"xc": (_lib.WS_XC, 3), "v": (_lib.WS_V, 3), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
-            "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3)}
+            "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3), "curv": (_lib.WS_CURV, 3), "xcbar": (_lib.WS_XCBAR, 3)}
 
     def __init__(self, eng: "Engine", pts, flags: int, m_color: int = 0):
         self.eng, self.pts, self.flags, self.M, self.m_color = eng, pts, flags, pts.M, int(m_color)
@@ -416,10 +416,11 @@ class PointCtx:
         return v
 
 
-def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0) -> PointCtx:
+def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, fp32_only: bool = False) -> PointCtx:
+    """``fp32_only``: keep the evaluation on the fp32 kernels in split-precision mode too (the point adjoint reads their mask words)."""
     ctx = PointCtx(self, pts, flags, m_color)
     save = bool(flags & _lib.PF_SAVE)
-    if self.split_precision and pts.M >= self.x3_infer_min and (self.x3_train_chain or not save):
+    if self.split_precision and pts.M >= self.x3_infer_min and (self.x3_train_chain or not save) and not fp32_only:
         # opt-in: the launches of a large evaluation in split precision -- csrc/infer_x3r.hip without PF_SAVE; with PF_SAVE the
         # split-precision TRAINING chain, whose workspace must go through es_point_backward_x3 (``ctx.x3_chain``)
         px3 = self.packed_x3(weff, bool(flags & _lib.PF_DEFORM))
@@ -460,6 +461,36 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, 
 
 
 Engine.point_backward = _point_backward
+
+
+def _point_input_adjoint(self, ctx: PointCtx, weff, packed, d_sdf, d_go):
+    """The adjoint of the QUERY POINTS through g_o (and only through g_o: callers that expose sdf as a function of the points attach
+    d sdf / d x = g_o themselves, renderer.EndoSurfNet.get_sdf_from_observed_space) -- the reference's create_graph=True second
+    derivative (endosurf.py:581-601, :603-619).  Call right after point_backward on the same context:
+        xbar = J^T xcbar - d_go * curv(g_c) - d_sdf * g_o        (include/endosurf_hip.h es_point_vjp; without a deformation network J = I)
+    where xcbar (the backward's adjoint of x_c) carries the Hessian-vector product of the SDF network along J d_go, the curvature term is
+    the deformation network's own second derivative, and the last term removes the sdf path's share of xcbar.  Overwrites the
+    workspace's g_c / g_o / curvature buffers."""
+    M = ctx.M
+    if ctx.x3_chain:
+        raise _lib.EndoSurfHipError("the point adjoint needs a workspace of the fp32 kernels (point_forward(..., fp32_only=True))")
+    xcbar = ctx.view("xcbar")
+    go = ctx.view("go").clone()
+    if ctx.flags & _lib.PF_DEFORM:
+        curv = ctx.view("curv").clone()
+        ctx.view("gc").copy_(xcbar)
+        check(self.lib.es_point_vjp(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, self.st()), "es_point_vjp")
+        xbar = ctx.view("go").clone()
+        if d_go is not None:
+            xbar -= d_go.detach().to(torch.float32).reshape(M, 3) * curv
+    else:
+        xbar = xcbar.clone()
+    if d_sdf is not None:
+        xbar -= d_sdf.detach().to(torch.float32).reshape(M, 1) * go
+    return xbar
+
+
+Engine.point_input_adjoint = _point_input_adjoint
 
 
 

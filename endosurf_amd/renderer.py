@@ -309,37 +309,42 @@ class EndoSurfNet(nn.Module):
             raise ValueError("t must hold one time per point (or a single shared time)")
         return x, (t.expand(x.shape[0]) if t.numel() == 1 else t).contiguous()
 
+    @staticmethod
+    def _wrt_points(x):
+        """``x`` if autograd should track the query points (a tensor that requires grad, with grad mode on), else None."""
+        return x if (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()) else None
+
     def get_sdf_from_observed_space(self, x, t):
         """sdf(x + deform(x, t)) [M,1]  (endosurf.py:570-579).
 
         If ``x`` requires grad (the reference's own pattern around this call is ``autograd.grad(sdf, x, create_graph=True)``,
-        endosurf.py:585-600) the result is ALSO differentiable w.r.t. the points to first order: d sdf / d x is the kernels' g_o = J^T g_c,
-        attached as ``sdf + <x - x.detach(), g_o>`` (value unchanged).  g_o itself carries the hand-written backward to the parameters, so
-        a loss on ``autograd.grad(sdf, x, create_graph=True)`` (an eikonal term on arbitrary points) back-propagates to the parameters
-        exactly like the reference's; the second derivative w.r.t. the POINTS (a Hessian-vector product) is not available: g_o is a
-        constant w.r.t. x in that graph."""
+        endosurf.py:585-600) the result is differentiable w.r.t. the points: d sdf / d x is the kernels' g_o = J^T g_c, attached as
+        ``sdf + <x - x.detach(), g_o>`` (value unchanged).  g_o itself carries the hand-written backward to the parameters AND (round 5)
+        to the points -- the Hessian-vector product of the query (Engine.point_input_adjoint) -- so a loss on
+        ``autograd.grad(sdf, x, create_graph=True)`` back-propagates to both, like the reference's."""
         r = self._r()
         with torch.cuda.device(r.device):
-            x_in = x
+            x_in = self._wrt_points(x)
             x, t = self._xt(x, t)
             weff, _ = r._weights()
-            wrt_x = torch.is_tensor(x_in) and x_in.requires_grad and torch.is_grad_enabled()
-            if wrt_x or (weff.requires_grad and torch.is_grad_enabled()):
-                sdf, g_o = r._point_eval(x, t)
-                if wrt_x:
+            if x_in is not None or (weff.requires_grad and torch.is_grad_enabled()):
+                sdf, g_o = r._point_eval(x, t, x_in=x_in)
+                if x_in is not None:
                     xr = x_in.to(torch.float32).reshape(-1, 3)
                     sdf = sdf + ((xr - xr.detach()) * g_o).sum(-1, keepdim=True)
                 return sdf
             return r.sdf_observed(x, t)
 
     def get_sdf_grad_from_observed_space(self, x, t):
-        """d sdf / d x at observed points [M,3] = J^T g_c  (endosurf.py:581-601).  Differentiable w.r.t. the parameters; a graph back to
-        the points (their Hessian) does not exist here -- asked for (``x.requires_grad``), that is said once instead of silently dropped."""
+        """d sdf / d x at observed points [M,3] = J^T g_c  (endosurf.py:581-601).  Differentiable w.r.t. the parameters and -- like the
+        reference's create_graph=True result -- w.r.t. the points (``autograd.grad(g.sum(), x)`` = the Hessian of the query times the
+        incoming adjoint: one more reverse sweep of the deformation network on the SDF backward's x_c adjoint, plus the deformation
+        network's own curvature term)."""
         r = self._r()
         with torch.cuda.device(r.device):
-            self._warn_points_detached(x, "get_sdf_grad_from_observed_space")
+            x_in = self._wrt_points(x)
             x, t = self._xt(x, t)
-            return r._point_eval(x, t)[1]
+            return r._point_eval(x, t, x_in=x_in)[1]
 
     _warned_detached = set()
 
@@ -353,12 +358,13 @@ class EndoSurfNet(nn.Module):
                           RuntimeWarning, stacklevel=3)
 
     def get_sdf_grad_from_canonical_space(self, x):
-        """d sdf / d x_c at canonical points [M,3]  (endosurf.py:603-619): the SDF network alone."""
+        """d sdf / d x_c at canonical points [M,3]  (endosurf.py:603-619): the SDF network alone.  Differentiable w.r.t. the parameters and
+        the points (the SDF network's Hessian-vector product comes out of its backward as the adjoint of x_c)."""
         r = self._r()
         with torch.cuda.device(r.device):
-            self._warn_points_detached(x, "get_sdf_grad_from_canonical_space")
+            x_in = self._wrt_points(x)
             x, t = self._xt(x, torch.zeros(1, device=x.device))
-            return r._point_eval(x, t, canonical=True)[1]
+            return r._point_eval(x, t, canonical=True, x_in=x_in)[1]
 
     def get_deform_grad_from_observed_space(self, x, t):
         """Jacobian d x_c / d x [M,3,3] (dim_out, dim_in)  (endosurf.py:621-658): three forward-mode tangents (J e_j), no grad."""
@@ -445,10 +451,16 @@ class _PointEvalFn(torch.autograd.Function):
     """Fused per-point evaluation (sdf, g_o[, rgb]) with hand-written backward to the effective weights."""
 
     @staticmethod
-    def forward(ctx, weff, packed, eng: Engine, pts, flags: int):
+    def forward(ctx, weff, packed, eng: Engine, pts, flags: int, x_in=None):
+        """``x_in`` (optional): the caller's point tensor, so that autograd routes the adjoint of the POINTS through g_o back to it
+        (colour-less evaluations on the fp32 kernels; ``flags`` must carry PF_SAVE)."""
         # grad mode is disabled inside Function.forward; the caller passes the save decision through ``flags``
-        pctx = eng.point_forward(pts, weff, packed, flags)
+        pctx = eng.point_forward(pts, weff, packed, flags, fp32_only=x_in is not None)
         ctx.pctx, ctx.eng, ctx.weff, ctx.packed = pctx, eng, weff, packed
+        ctx.pts, ctx.flags = pts, flags
+        ctx.wrt_x = x_in is not None
+        ctx.x_shape = tuple(x_in.shape) if x_in is not None else None
+        ctx.x_dtype = x_in.dtype if x_in is not None else None
         outs = [pctx.view("sdf").clone(), pctx.view("go").clone()]     # own storage: outputs must not pin the workspace
         if flags & _lib.PF_COLOR:
             outs.append(pctx.view("rgb").clone())
@@ -457,11 +469,20 @@ class _PointEvalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_sdf, d_go, d_rgb=None):
         eng, pctx = ctx.eng, ctx.pctx
-        if not (pctx.flags & _lib.PF_SAVE):
+        if not (ctx.flags & _lib.PF_SAVE):
             raise RuntimeError("point evaluation was run without PF_SAVE; cannot backpropagate")
+        if pctx is None:
+            # second backward through the same node (retain_graph / the reference's autograd.grad(sdf, x, create_graph=True) followed by
+            # loss.backward(): with point-differentiable outputs the first pass already went through here).  The backward kernels consume
+            # the workspace, so the forward is evaluated again -- same kernels, same inputs, same values.
+            with torch.no_grad():
+                pctx = eng.point_forward(ctx.pts, ctx.weff.detach(), ctx.packed, ctx.flags, fp32_only=ctx.wrt_x)
         dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, d_rgb)
+        xbar = None
+        if ctx.wrt_x and ctx.needs_input_grad[5]:
+            xbar = eng.point_input_adjoint(pctx, ctx.weff, ctx.packed, d_sdf, d_go).reshape(ctx.x_shape).to(ctx.x_dtype)
         ctx.pctx = None
-        return dweff, None, None, None, None
+        return dweff, None, None, None, None, xbar
 
 
 class _RenderFn(torch.autograd.Function):
@@ -877,15 +898,21 @@ class EndoSurfRenderer(nn.Module):
                 "weights": weights, "weight_max": wmax, "s_val": s_val, "aux_sdf": aux_sdf, "aux_gradients_o": aux_go, "eik_den": eik_den}
 
     # ---- auxiliary losses (reference endosurf.py:289-342) ------------------------------------------------------------
-    def _point_eval(self, x, t, dirs=None, canonical=False):
-        """(sdf [M,1], g_o [M,3]) at explicit points; ``canonical``: x is a canonical-space point (SDF network only, g_o = g_c)."""
+    def _point_eval(self, x, t, dirs=None, canonical=False, x_in=None):
+        """(sdf [M,1], g_o [M,3]) at explicit points; ``canonical``: x is a canonical-space point (SDF network only, g_o = g_c).
+        ``x_in``: the caller's point tensor [M,3] when it requires grad: g_o then carries its backward to the POINTS as well
+        (d <g_o, w> / d x, the reference's create_graph=True second derivative); the returned sdf does NOT (callers attach d sdf / d x
+        = g_o themselves)."""
         weff, packed = self._weights()
         pts = self.engine.points(x=x.detach().to(torch.float32).contiguous(), t=t.detach().to(torch.float32).reshape(-1).contiguous(),
                                  dirs=dirs)
         flags = self._flags(weff)
         if canonical:
             flags &= ~_lib.PF_DEFORM
-        sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, flags)
+        if x_in is not None:
+            sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, flags | _lib.PF_SAVE, x_in)
+        else:
+            sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, flags)
         return sdf, g_o
 
     @_on_device

@@ -148,8 +148,11 @@ def test_sdf_query_is_differentiable_wrt_points_first_order(mode, use_deform):
     assert float((h_sdf.double().cpu() - o_sdf).abs().max()) < 1e-5
     assert float((h_g.double().cpu() - o_g).abs().max()) < 1e-4
     assert abs(h_loss - o_loss) < 1e-5 * max(1.0, abs(o_loss))
-    # first-order gradient w.r.t. the points themselves: d loss / d x holds the sdf term's share only (g_o is a constant w.r.t. x here)
-    assert x32.grad is not None and float((x32.grad.double().cpu() - 0.3 / M * o_g).abs().max()) < 1e-6
+    # the gradient w.r.t. the points themselves: the sdf term's share (0.3 / M g_o) AND, since round 5, the eikonal term's -- the
+    # Hessian-vector product of the query that the reference gets from create_graph=True (Engine.point_input_adjoint)
+    xg_h, xg_o = x32.grad.double().cpu(), x64.grad
+    assert float((xg_h - xg_o).norm() / xg_o.norm()) < 1e-4, float((xg_h - xg_o).norm() / xg_o.norm())
+    assert float((xg_o - 0.3 / M * o_g).norm() / xg_o.norm()) > 0.1          # (the second-order share is not negligible in this check)
     named = dict(r.named_parameters())
     keys = ["sdf_network.net.0.weight_v", "sdf_network.net.4.weight_g", "sdf_network.net.7.bias"] + (
         ["deform_network.net.1.weight_v", "deform_network.net.6.bias"] if use_deform else [])
@@ -157,6 +160,54 @@ def test_sdf_query_is_differentiable_wrt_points_first_order(mode, use_deform):
         gh, go = named["model." + k].grad.double().cpu(), params[k].grad
         rel = float((gh - go).norm() / (go.norm() + 1e-30))
         assert rel < 2e-3, (k, rel)
+
+
+@pytest.mark.parametrize("mode,use_deform,canonical", [("trained", True, False), ("init", True, False), ("trained", False, False),
+                                                       ("trained", True, True)])
+def test_sdf_gradient_query_is_differentiable_wrt_points(mode, use_deform, canonical):
+    """get_sdf_grad_from_observed_space / get_sdf_grad_from_canonical_space return their gradient with create_graph=True in the reference
+    (endosurf.py:598, :616): ``autograd.grad(<g, w>, x)`` is the Hessian of the query times w.  HIP: J^T xcbar - w * curv(g_c)
+    (es_point_vjp on the x_c adjoint of es_point_backward; xcbar itself without a deformation network).  Against autograd through the
+    fp64 oracle, 1e-4 relative, together with the parameter gradients of the same backward; and no RuntimeWarning about detached points."""
+    import warnings
+    import weightgen
+    from oracle import endosurf_oracle as O
+    seed, M = 13, 200
+    r = renderer_for(seed, mode, use_deform)
+    state = weightgen.make_state(seed, mode, use_deform)
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state.items()}
+    net = O.OracleNet(params, use_deform)
+    rng = np.random.default_rng(6)
+    x_np = rng.uniform(-0.8, 0.8, size=(M, 3)).astype(np.float32)
+    t_np = rng.uniform(0.0, 1.0, size=(M, 1)).astype(np.float32)
+    w_np = rng.normal(size=(M, 3)).astype(np.float32)
+
+    x64 = torch.from_numpy(x_np).double().requires_grad_(True)
+    if canonical:
+        sdf64 = net.sdf_net(x64, with_grad=False)[0]
+    else:
+        sdf64 = net.sdf_observed(x64, torch.from_numpy(t_np).double())
+    (g64,) = torch.autograd.grad(sdf64.sum(), x64, create_graph=True)
+    (g64 * torch.from_numpy(w_np).double()).sum().backward()
+
+    for p in r.parameters():
+        p.grad = None
+    x32 = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        g32 = (r.model.get_sdf_grad_from_canonical_space(x32) if canonical
+               else r.model.get_sdf_grad_from_observed_space(x32, torch.from_numpy(t_np).cuda()))
+    assert g32.requires_grad and float((g32.detach().double().cpu() - g64.detach()).abs().max()) < 1e-4
+    (g32 * torch.from_numpy(w_np).cuda()).sum().backward()
+    xh, xo = x32.grad.double().cpu(), x64.grad
+    rel = float((xh - xo).norm() / xo.norm())
+    assert rel < 1e-4, rel
+    named = dict(r.named_parameters())
+    keys = ["sdf_network.net.0.weight_v", "sdf_network.net.4.weight_g", "sdf_network.net.7.bias"] + (
+        ["deform_network.net.1.weight_v", "deform_network.net.6.bias"] if use_deform and not canonical else [])
+    for k in keys:
+        gh, go = named["model." + k].grad.double().cpu(), params[k].grad
+        assert float((gh - go).norm() / (go.norm() + 1e-30)) < 2e-3, k
 
 
 def test_parameter_rebinding_is_detected():
