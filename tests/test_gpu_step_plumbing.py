@@ -111,3 +111,37 @@ def test_drawn_step_is_reproducible_from_the_torch_seed():
             loss, _, _ = tr.train_step(b, it + 1)
         out.append(float(loss))
     assert out[0] == out[1]
+
+
+def test_param_grads_between_steps_and_graph_rng_space():
+    """What a user of Trainer.train_step may rely on ("gradients of a Trainer step"): after a step every parameter's
+    ``.grad`` is a view of the step's flat gradient (valid, finite, non-zero) until the NEXT step begins; a view kept across steps is
+    overwritten then (the step arena is one block, cleared and refilled by every step), so gradients that must survive are cloned.
+    And the random draws of graph-mode steps come from a subsequence space disjoint from the eager steps' (ADVICE r4)."""
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+    r = renderer_for(5, "trained", True)
+    tr = Trainer(r, lr=1e-3)
+    sc = SyntheticScene("cuda", seed=3)
+    tr.update_learning_rate(100)
+    tr.train_step(sc.batch(128), 100)
+    named = dict(r.named_parameters())
+    p = named["model.sdf_network.net.3.weight_v"]
+    flat = tr.optimizer.flat_grad()
+    off = r.model._layout["sdf_network.net.3.weight_v"][0]
+    assert p.grad is not None and p.grad.data_ptr() == flat.data_ptr() + 4 * off          # a view of the step's flat buffer
+    g1 = p.grad.clone()
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    kept = p.grad
+    tr.train_step(sc.batch(128), 101)
+    assert not torch.equal(kept, g1)                      # the retained view was overwritten by the next step ...
+    assert torch.equal(kept, p.grad) or p.grad.data_ptr() != kept.data_ptr()       # ... (it is that step's gradient, or a dead slice)
+    # eager draws: subsequence = call index; graph-mode draws: 2^63 + device step counter -- never the same stream
+    eng = r.engine
+    torch.manual_seed(11)
+    eng._rng_calls = 4
+    step = torch.tensor([4.0, 0.0], dtype=torch.float64, device="cuda")
+    a = eng.uniform(64).cpu()
+    b = eng.uniform(64, step).cpu()
+    assert not torch.equal(a, b)
+    seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    assert np.array_equal(b.numpy(), np.array(philox_uniform(64, seed, (1 << 63) + 4), np.float32))
