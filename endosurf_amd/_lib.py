@@ -113,7 +113,8 @@ PROTOTYPES = {
 ABI_VERSION = 7
 QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
-WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB, WS_CURV, WS_XCBAR = range(9)
+WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
+WS_XCBAR, WS_CURV = 27, 34          # (include/endosurf_hip.h ES_WS_XCBAR / ES_WS_CURV)
 
 _lib = None
 

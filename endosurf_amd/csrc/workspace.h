@@ -25,10 +25,6 @@ constexpr int PF_X3 = 8;       // OPT-IN: weight-gradient GEMMs in split precisi
 enum WsBuf : int {
     // forward outputs
     WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB,      // WS_V = J d (3 per point)
-    WS_CURV,       // [Mp][3]  c_j = sum_i 4^i (ebar_sin(i,j) sin(2^i x_j) + ebar_cos(i,j) cos(2^i x_j)), ebar = the adjoint of the deformation
-                   //          network's encoding input for the covector in WS_GC: minus the diagonal of sum_k g_c[k] d2 x_c[k] / dx^2 (the
-                   //          encodings act per coordinate).  Written by the VJP sweep; the second-order term of d g_o / d x (es_point_vjp)
-    WS_XCBAR,      // [Mp][3]  backward: the adjoint of x_c (all paths)
     // forward saves
     WS_S_ACT,      // [8][Mp][256]  s_1..s_8 (softplus outputs; always written: the SDF reverse sweep needs them); fragment order
     WS_D_U0,       // [2Mp][64]     deform encoding rows (52 valid)
@@ -51,14 +47,19 @@ enum WsBuf : int {
     WS_S_TAU0,     // [Mp][64]
     WS_S_TAU,      // [8][Mp][256]  tau_1..tau_8; fragment order
     WS_S_ZB,       // [8][Mp][256]  second-order terms, overwritten in place by the adjoints of z_0..7; fragment order
+    WS_XCBAR,      // [Mp][3]       the adjoint of x_c over all paths (public id ES_WS_XCBAR: the point adjoint reads it, es_point_vjp)
     WS_JU,         // [Mp][3]       J gbar_o (adjoint of g_c through g_o = J^T g_c)
     WS_D_T0,       // [Mp][64]      tangent sweep along gbar_o: encoding tangent (52 valid)
     WS_D_T,        // [8][Mp][256]  tau_1..tau_8
     WS_D_A,        // [8][2Mp][256] adjoints of deform pre-activations a_0..7 (value row, J d row)
     WS_D_A8,       // [2Mp][4]
     WS_C_SBAR,     // [Mp][128]     adjoint of the colour input's small part (93 valid)
+    WS_CURV,       // [Mp][3]  c_j = sum_i 4^i (ebar_sin(i,j) sin(2^i x_j) + ebar_cos(i,j) cos(2^i x_j)), ebar = the adjoint of the deformation
+                   //          network's encoding input for the covector in WS_GC: minus the diagonal of sum_k g_c[k] d2 x_c[k] / dx^2 (the
+                   //          encodings act per coordinate).  Written by the VJP sweep; the second-order term of d g_o / d x (es_point_vjp)
     WS_COUNT
 };
+static_assert(WS_XCBAR == 27 && WS_CURV == 34, "public buffer ids of include/endosurf_hip.h (ES_WS_XCBAR, ES_WS_CURV)");
 
 struct WsLayout {
     size_t off[WS_COUNT + 1];

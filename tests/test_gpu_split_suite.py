@@ -37,8 +37,8 @@ def init(self, device):
         self.x3_infer_min = 1
 E.Engine.__init__ = init
 _pf = E.Engine.point_forward
-def pf(self, pts, weff, packed, flags, m_color=0):
-    ctx = _pf(self, pts, weff, packed, flags, m_color)
+def pf(self, pts, weff, packed, flags, m_color=0, **kw):
+    ctx = _pf(self, pts, weff, packed, flags, m_color, **kw)
     seen["chain"] += int(bool(ctx.x3_chain))
     return ctx
 E.Engine.point_forward = pf
