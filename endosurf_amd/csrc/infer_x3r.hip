@@ -111,7 +111,7 @@ __device__ __forceinline__ void deform_jvp_x3r_body(const PointSrc& src, const T
             const int f = 32 * b + 8 * q + 4 * hi + i;
             const float z = P[b][4 * q + i];
             const bool m = value_row(z) > 0.f;               // ReLU mask of the VALUE column gates both
-            mask_set(mk, b, 4 * q + i, m);
+            mask_set_now(mk, b, 4 * q + i, m);
             const float h = m ? z : 0.f;
             if (32 * b + 8 * q + 4 + i < 204) return h;
             return (skip && f >= 204) ? erow[f - 204] : h;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void deform_jvp_x3r_body(const PointSrc& src, const T
                     const int r = 4 * q + i, f = 32 * b + 8 * q + 4 * hi + i;
                     const float z = P[b][r];
                     const bool m = value_row(z) > 0.f;
-                    mask_set(mk, b, r, m);
+                    mask_set_now(mk, b, r, m);
                     const float h = m ? z : 0.f;
                     h4[i] = h;
                     d0 = fmaf(w8L[f], h, d0); d1 = fmaf(w8L[256 + f], h, d1); d2 = fmaf(w8L[512 + f], h, d2);

@@ -310,6 +310,14 @@ struct RowTile {
 
 // mask bit of register r of feature block b inside the 128-bit word of a (layer, point, lane half)
 __device__ __forceinline__ void mask_set(u32x4& mk, int b, int r, bool m) { mk[b >> 1] |= (m ? 1u : 0u) << ((b & 1) * 16 + r); }
+// mask_set whose or is DONE before the next statement: the empty volatile asm on the word is an anchor the scheduler cannot move the
+// or (and hence the comparison's 64-bit lane mask, an SGPR pair) past.  Left to itself the compiler deferred the 32 ors of a k-step and
+// kept their lane masks alive: 371-387 SGPR spills (v_writelane / v_readlane + hazard nops) in k_deform_jvp_x3r.
+__device__ __forceinline__ void mask_set_now(u32x4& mk, int b, int r, bool m) {
+    unsigned w = mk[b >> 1] | ((m ? 1u : 0u) << ((b & 1) * 16 + r));
+    asm volatile("" : "+v"(w));
+    mk[b >> 1] = w;
+}
 __device__ __forceinline__ bool mask_get(const u32x4& mk, int b, int r) { return (mk[b >> 1] >> ((b & 1) * 16 + r)) & 1u; }
 
 // the element of the VALUE column of this lane's point: lanes 0-15 of a lane half keep their own, lanes 16-31 get their partner's
