@@ -65,3 +65,46 @@ def test_graph_step_random_draws_and_recapture_on_a_new_shape():
     g0 = tr._graph["graph"]
     tr.train_step_graph(sc.batch(128), 7)
     assert tr._graph["graph"] is None and tr._graph["key"][0] == (128, 9) and g0 is not None
+
+
+def test_captured_step_survives_a_regrown_arena():
+    """the step arena's address is baked into a captured step (its memset and every launch that uses a slice of it).
+    An eager step with a LARGER batch makes the engine allocate a new arena; the graph keeps the old block alive, so later replays
+    neither write into recycled memory nor see other tensors' data: the replayed trajectory equals that of a trainer that never left
+    the graph."""
+    from endosurf_amd.trainer import SyntheticScene, Trainer
+
+    def run(interleave):
+        r = renderer_for(5, "trained", True)
+        r.engine.deterministic = True
+        tr = Trainer(r, lr=1e-3, n_iter=40, warm_up_end=4)
+        sc = SyntheticScene("cuda", seed=9)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+        small = [sc.batch(128) for _ in range(6)]
+        for b in small:
+            b["u_perturb"] = torch.rand(128, 1, device="cuda", generator=gen)
+            b["u_neigh"] = torch.rand(128, 3, device="cuda", generator=gen)
+        big = sc.batch(1024)
+        losses = []
+        for it, b in enumerate(small, 1):
+            losses.append(float(tr.train_step_graph(b, it)))
+            if interleave and it == 4:
+                assert tr._graph["graph"] is not None
+                arena0 = r.engine._arena
+                flat0 = r.model._flat.detach().clone()
+                opt_state = (tr.optimizer.exp_avg.clone(), tr.optimizer.exp_avg_sq.clone(), tr.optimizer.step_count)
+                tr.train_step(big, it)                          # larger batch: the engine needs (and allocates) a larger arena
+                assert r.engine._arena is not arena0 and tr._graph["arena"] is arena0
+                junk = [torch.full((arena0.numel(),), float("nan"), device="cuda") for _ in range(2)]      # would land in a freed arena
+                # undo the eager step's update so that both trajectories see the same parameters / moments
+                with torch.no_grad():
+                    r.model._flat.copy_(flat0)
+                tr.optimizer.exp_avg.copy_(opt_state[0]); tr.optimizer.exp_avg_sq.copy_(opt_state[1]); tr.optimizer.step_count = opt_state[2]
+                r.model._epoch += 1
+                del junk
+        return np.array(losses), r.model._flat.detach().clone()
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert np.all(np.isfinite(lb)) and np.allclose(la, lb, rtol=1e-6, atol=1e-7), (la, lb)
+    assert float((pa - pb).abs().max()) <= 1e-6 * float(pa.abs().max())
