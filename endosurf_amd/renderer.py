@@ -735,6 +735,8 @@ class EndoSurfRenderer(nn.Module):
             self.__dict__["_fwd_graph"] = dict(key=key, graph=None)
             return None
         cos = self.get_cos_anneal_ratio(iter_step)
+        if g["graph"] is False:          # a capture of this key failed before: stay eager
+            return None
         if g["graph"] is None:
             static_in = eng.empty(*rays.shape)
             static_in.copy_(self._rays32(rays))
@@ -747,6 +749,12 @@ class EndoSurfRenderer(nn.Module):
                     ret = self.render_rays(static_in, **kw)
                     names = sorted(ret)
                     flat = torch.cat([ret[k].reshape(-1) for k in names])
+            except Exception as e:       # (e.g. another thread used the device during the capture): this key stays eager, said once
+                g["graph"] = False
+                import warnings
+                warnings.warn(f"endosurf_amd: capturing the no-grad forward failed ({type(e).__name__}: {e}); it stays eager for this shape",
+                              RuntimeWarning, stacklevel=3)
+                return None
             finally:
                 self._cos_anneal_dev = None
             g.update(graph=graph, static_in=static_in, cos_dev=cos_dev, cos=float(cos), flat=flat,
