@@ -236,3 +236,52 @@ def test_philox_reference_known_answers():
     assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_rank_pinning_gives_disjoint_core_sets_within_the_allowed_mask():
+    """parallel.pin_rank_to_cores (bench.py --gpus N, cold-run kit): every local rank gets its own contiguous run of the cores this
+    process may use -- never a core outside that mask -- and fewer cores than ranks means nothing is pinned (and the result says why)."""
+    import os
+    from endosurf_amd import parallel
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity")
+    allowed = sorted(os.sched_getaffinity(0))
+    threads = torch.get_num_threads()
+    try:
+        world = 2 if len(allowed) >= 2 else 1
+        got = []
+        for local in range(world):
+            os.sched_setaffinity(0, allowed)
+            info = parallel.pin_rank_to_cores(local, world)
+            mine = sorted(os.sched_getaffinity(0))
+            got.append((info, mine))
+        if world == 1:
+            assert got[0][0]["pinned"] is False and "reason" in got[0][0]
+        else:
+            (i0, c0), (i1, c1) = got
+            assert i0["pinned"] and i1["pinned"] and not (set(c0) & set(c1)) and set(c0) | set(c1) <= set(allowed)
+            assert i0["cores"] == len(c0) == len(allowed) // 2 and (i0["first"], i0["last"]) == (c0[0], c0[-1]) and c0[-1] < c1[0]
+        os.sched_setaffinity(0, allowed)
+        too_many = parallel.pin_rank_to_cores(0, len(allowed) + 1)
+        assert too_many["pinned"] is False and str(len(allowed)) in too_many["reason"] and sorted(os.sched_getaffinity(0)) == allowed
+    finally:
+        os.sched_setaffinity(0, allowed)
+        torch.set_num_threads(threads)
+
+
+def test_pmc_figures_are_per_single_launch_and_plausible():
+    """bench.pmc_info / pmc_rates: a symbol with several (instantiation, grid) rows -- k_query_sdf's marching and
+    coarse launches -- is reported per SINGLE launch (launch-weighted mean), and rates that no MI355X can show are withheld, not printed."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    pm = bench.pmc_info("k_query_sdf")
+    assert pm is not None and len(pm["rows"]) >= 2
+    per = [r["hbm_bytes"] for r in pm["rows"]]
+    assert min(per) <= pm["hbm_bytes"] <= max(per) and 30e6 < pm["hbm_bytes"] < 40e6          # ~34 MB: 8 L2 fills of the weight pack
+    n = sum(r["launches"] for r in pm["rows"])
+    assert abs(pm["cycles"] - sum(r["cycles"] * r["launches"] for r in pm["rows"]) / n) < 1
+    gbps, ghz, note = bench.pmc_rates(pm, 1.283)
+    assert note is None and 1.0 <= ghz <= 2.6 and gbps < 100
+    assert bench.pmc_rates(pm, 0.6)[2] is not None and bench.pmc_rates(pm, 0.6)[:2] == (None, None)       # 4.7 GHz: withheld
