@@ -268,8 +268,9 @@ def free_port():
 class Ctx:
     """What every workload of one bench.py process shares: the rank's device and the process group."""
 
-    def __init__(self, dev, rank, world, dist_on, force_dist, backend, schedule):
+    def __init__(self, dev, rank, world, dist_on, force_dist, backend, schedule, overlap_allreduce=False):
         self.dev, self.rank, self.world, self.dist_on, self.force_dist, self.backend, self.schedule = dev, rank, world, dist_on, force_dist, backend, schedule
+        self.overlap_allreduce = bool(overlap_allreduce)
 
     def barrier(self):
         import torch
@@ -325,7 +326,8 @@ class Workload:
         self.renderer = EndoSurfRenderer(render_cfg(cfg), dict(NET_CFG, use_deform=cfg["use_deform"]), device=ctx.dev)
         if split:
             self.renderer.engine.split_precision = True
-        self.trainer = Trainer(self.renderer, data_parallel=ctx.dist_on, schedule=ctx.schedule, force_collective=ctx.force_dist)
+        self.trainer = Trainer(self.renderer, data_parallel=ctx.dist_on, schedule=ctx.schedule, force_collective=ctx.force_dist,
+                               overlap_allreduce=ctx.overlap_allreduce)
         parallel.broadcast_parameters(self.trainer.params)
         self.scene = SyntheticScene(ctx.dev, seed=1234 + ctx.rank)
         self.eng = self.renderer.engine
@@ -565,6 +567,20 @@ def collective_proof(ctx, wl, dt_local):
         wl.trainer.allreduce_events = None
         if ts:
             in_step = ctx.max_over_ranks(sorted(ts)[len(ts) // 2])
+    # the OTHER all-reduce mode on a few steps (pipelined buckets if the run used one bucket, and vice versa): the comparison a cold
+    # N > 1 run needs in order to decide the default, at the price of ~10 steps
+    other = None
+    if wl.mode == "train" and not wl.use_graph and dist.get_world_size() > 1:
+        tr = wl.trainer
+        tr.overlap_allreduce = not tr.overlap_allreduce
+        try:
+            for i in range(3):
+                wl.step(20_000 + i)
+            dto, _ = wl.timed(20_003, 8)
+            other = dict(overlap_allreduce=tr.overlap_allreduce, ms_per_step=dto / 8 * 1e3, steps=8,
+                         pipelined_steps=int(tr.pipelined_steps))
+        finally:
+            tr.overlap_allreduce = not tr.overlap_allreduce
     # the replicas after all the steps above: every rank's flat parameter buffer against rank 0's, bit for bit (the summed bucket and the
     # update are the same on every rank, so any difference is a bug)
     mine = wl.renderer.model._flat.detach()
@@ -574,10 +590,12 @@ def collective_proof(ctx, wl, dt_local):
     dist.all_reduce(diff)
     return dict(ranks_seen_by_collective=int(round(float(ones.item()))), bucket_bytes=4 * wl.eng.n_param,
                 replicas_bit_identical=bool(float(diff.item()) == 0.0), replica_words_differing=int(diff.item()),
-                allreduce_ms=ar_ms, allreduce_in_step_ms=in_step, allreduce_exposed_ms=in_step, allreduce_hidden_ms=0.0 if in_step is not None else None,
+                allreduce_ms=ar_ms, allreduce_other_mode=other, allreduce_in_step_ms=in_step, allreduce_exposed_ms=in_step,
+                allreduce_hidden_ms=(None if in_step is None else (max(0.0, ar_ms - in_step) if wl.trainer.overlap_allreduce else 0.0)),
                 allreduce_overlap_note="exposed = the collective as the step's launch stream sees it (median of 4 steps, MAX over ranks): the bucket is "
-                "complete only behind the last backward launch and Adam needs all of it, so nothing of a step can hide it (hidden = 0); a "
-                "per-network bucket pipeline is described in DESIGN 5 and not built",
+                "complete only behind the last backward launch and Adam needs all of it, so nothing of a ONE-bucket step can hide it (hidden = 0); "
+                "--overlap-allreduce issues two of three buckets on a side stream under the remaining weight-gradient launches (DESIGN 6): "
+                "allreduce_other_mode times a few steps of the mode this run did not use",
                 allreduce_note="mean of %d back-to-back all-reduces of the 6.6 MB flat gradient bucket, HIP events on the "
                 "launch stream, MAX over ranks (in a step it is issued once, after the last weight-gradient launch)" % n,
                 per_rank_seconds=per_rank)
@@ -656,6 +674,9 @@ def main():
     ap.add_argument("--graph-probe", action="store_true",
                     help="also time the step replayed from the whole-step hipGraph and apply the host-bound fallback rule (always on at N > 1)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to disjoint host-core sets")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="data-parallel training: the gradient all-reduce as a pipeline of three buckets, two of them on a side stream under "
+                         "the remaining weight-gradient launches (Trainer(overlap_allreduce=True); opt-in until a multi-GPU run has measured it)")
     ap.add_argument("--chunk", type=int, default=2048, help="frame mode: rays per chunk (the reference's demo.ray_batch is 2048)")
     args = ap.parse_args()
 
@@ -688,7 +709,7 @@ def main():
     local = parallel.local_device(local, world) if (world == 1 or backend == "nccl") else local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    ctx = Ctx(dev, rank, world, dist_on, force_dist, backend, args.schedule)
+    ctx = Ctx(dev, rank, world, dist_on, force_dist, backend, args.schedule, overlap_allreduce=args.overlap_allreduce)
     # cold-run kit: every local rank on its own host cores (within the mask this process was given)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     affinity = (parallel.pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), local_world) if world > 1 and not args.no_pin
@@ -725,7 +746,7 @@ def main():
                                collective=("rccl all-reduce forced at world 1" if force_dist else (
                                    ("%s all-reduce of the flat 6.6 MB gradient bucket per step" % backend) if world > 1 and mode == "train" else (
                                        "%s all-gather of the row slabs per frame" % backend if world > 1 and mode == "frame" else None))),
-                               samples_per_ray=wl.S, parallelism=f"dp{world}",
+                               samples_per_ray=wl.S, parallelism=f"dp{world}", overlap_allreduce=bool(args.overlap_allreduce),
                                weights="reference init, torch.manual_seed(0)", algorithmic_gflop_per_ray=algorithmic_gflop_per_ray(cfg)),
                    ms_per_step_min=min(per_rank_ms), ms_per_step_max=max(per_rank_ms),
                    ranks_seen_by_collective=proof["ranks_seen_by_collective"] if proof else None,

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_color_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _P]),
     "es_point_vjp": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
+    "es_point_backward_stages": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "es_weightnorm_backward_layers": (_I, [_P, _P, _P, _I, _I, _P]),
     "es_point_forward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P]),
     "es_gemm_atb": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "es_point_backward_x3": (_I, [C.POINTER(es_points), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -114,6 +116,7 @@ ABI_VERSION = 7
 QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
+BWD_CHAINS, BWD_WGRAD_DEFORM, BWD_WGRAD_SDF, BWD_WGRAD_COLOR = 1, 2, 4, 8          # es_point_backward_stages
 WS_XCBAR, WS_CURV = 27, 34          # (include/endosurf_hip.h ES_WS_XCBAR / ES_WS_CURV)
 
 _lib = None

@@ -11,6 +11,7 @@
 namespace es {
 int weightnorm_pack(const float* params, float* weff, float* packed, int use_deform, hipStream_t st);
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st);
+int weightnorm_backward_layers(const float* params, const float* dweff, float* dparams, int first_layer, int n_layers, hipStream_t st);
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out = 0, const int* ray_done = nullptr, int tile_points = 0);
 int march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, hipStream_t st);
@@ -26,7 +27,7 @@ int color_forward(const PointSrc& src, const float* packed, const float* weff, f
 int point_vjp(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
                           const float* d_sdf, const float* d_go, const float* d_rgb, hipStream_t st, const void* packed_x3 = nullptr);
-int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st);
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st, int net_mask = 7);
 size_t wgrad_det_floats();
 int gemm_atb(const float* X, const float* dA, int M, float* out, int x3, float* det, hipStream_t st);
 int train_loss(const LossArgs& a, hipStream_t st);
@@ -131,6 +132,12 @@ int es_weightnorm_pack(const float* params, float* weff, float* packed, int use_
 int es_weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, void* stream) {
     ES_REQUIRE(params && dweff && dparams, "null buffer");
     return weightnorm_backward(params, dweff, dparams, use_deform, (hipStream_t)stream);
+}
+
+int es_weightnorm_backward_layers(const float* params, const float* dweff, float* dparams, int first_layer, int n_layers, void* stream) {
+    ES_REQUIRE(params && dweff && dparams, "null buffer");
+    ES_REQUIRE(first_layer >= 0 && n_layers >= 0 && first_layer + n_layers <= NETS * LAYERS, "layers [first, first + n) of the 27 (network x 9 + layer)");
+    return weightnorm_backward_layers(params, dweff, dparams, first_layer, n_layers, (hipStream_t)stream);
 }
 
 int es_query_sdf(const es_points* pts, const float* packed, const float* weff, float* sdf_out, int use_deform, void* stream) {
@@ -287,6 +294,20 @@ int es_point_backward(const es_points* pts, const float* packed, const float* we
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
     return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, nullptr, (hipStream_t)stream);
+}
+int es_point_backward_stages(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color,
+                             const float* d_sdf, const float* d_go, const float* d_rgb, float* dweff, float* wg_scratch, int stages, void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(flags & ES_PF_SAVE, "es_point_backward_stages needs a workspace produced with ES_PF_SAVE");
+    ES_REQUIRE(!(flags & ES_PF_X3_CHAIN), "the staged backward is the fp32 family's (a workspace of es_point_forward)");
+    ES_REQUIRE(packed && weff && dweff && (pts->M == 0 || (ws && d_sdf && d_go)), "null buffer");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || d_rgb || pts->M == 0, "colour adjoint missing");
+    ES_REQUIRE(stages > 0 && stages < 16, "stages: ES_BWD_CHAINS | ES_BWD_WGRAD_DEFORM | ES_BWD_WGRAD_SDF | ES_BWD_WGRAD_COLOR");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    if (stages & ES_BWD_CHAINS)
+        if (int e = point_backward_chains(to_src(pts), packed, weff, ws, flags, m_color, d_sdf, d_go, d_rgb, (hipStream_t)stream)) return e;
+    if (stages >> 1) return point_wgrad(pts->M, ws, flags, m_color, d_sdf, dweff, wg_scratch, (hipStream_t)stream, stages >> 1);
+    return ST_OK;
 }
 int64_t es_wgrad_scratch_floats(void) { return (int64_t)wgrad_det_floats(); }
 int es_gemm_atb(const float* X, const float* dA, int M, float* out, int split_precision, float* wg_scratch, void* stream) {

@@ -183,6 +183,15 @@ int weightnorm_pack(const float* params, float* weff, float* packed, int use_def
     return hip_last("weightnorm_pack");
 }
 
+// layers [first_layer, first_layer + n_layers) of the 27 (3 networks x 9) only: the pieces of a pipelined gradient all-reduce
+int weightnorm_backward_layers(const float* params, const float* dweff, float* dparams, int first_layer, int n_layers, hipStream_t st) {
+    if (int e = init_tables()) return e;
+    if (n_layers <= 0) return ST_OK;
+    dim3 g1(65, n_layers);
+    hipLaunchKernelGGL(k_weightnorm_bwd, g1, dim3(256), 0, st, params, dweff, dparams, first_layer);
+    return hip_last("weightnorm_backward_layers");
+}
+
 int weightnorm_backward(const float* params, const float* dweff, float* dparams, int use_deform, hipStream_t st) {
     if (int e = init_tables()) return e;
     const int first_layer = use_deform ? 0 : LAYERS;

@@ -824,7 +824,9 @@ int gemm_atb(const float* X, const float* dA, int M, float* out, int x3, float* 
 }
 // All weight gradients of one point evaluation, accumulated (+=) into dweff (es_weff layout).
 // ``det`` (nullable): scratch of wgrad_det_floats() floats => deterministic reduction instead of fp32 atomics.
-int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st) {
+// net_mask: bit n = launch network n's group (deform, sdf, colour); 7 = all (es_point_backward).  The groups are independent launches that
+// accumulate into disjoint parts of dweff -- except the deformation network's LAST layer, whose slices ride in the sdf and colour launches.
+int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, float* dweff, float* det, hipStream_t st, int net_mask) {
     if (M <= 0) return ST_OK;
     const WsLayout L = ws_layout(M, flags);
     const Tabs tb = make_tabs();
@@ -846,7 +848,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
                    int x_frag = 0, int a_frag = 0) {
         g[n++] = WgProb{X, dA, out, bias, ldx, lda, ldo, rows, K, N, bstride, 0, x_frag, a_frag, 0};
     };
-    if (flags & PF_DEFORM) {
+    if ((flags & PF_DEFORM) && (net_mask & 1)) {
         // value + J d rows: (u_l, abar_l) over 2 rows per point (bias gradient from the value rows only); VJP / tangent pair:
         // (tau_l, r_l) over 1 row per point (g_o = J^T g_c is linear in every W_l: dW_l += r_l tau_l^T)
         const int R = 2 * Mp;
@@ -863,7 +865,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         // the deformation launch (the longest) stays a pure GEMM: its last layer's slices ride with the two shorter launches
         if (int e = launch_group(g, n, sm, 0, x3 ? KID_WGRAD_D_X3 : KID_WGRAD_D, M, det, x3, st)) return e;
     }
-    {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
+    if (net_mask & 2) {   // SDF: value-pass pairs (s_l, zbar_l) and reverse-pass pairs (tau_l, rho_l); the four [8][Mp][256] stacks of the SDF
         // kernels (s, rho, tau, zbar) are fragment-ordered: the fp32 SDF kernels, which write them in both kernel families, load AND
         // store them in their epilogues (one dwordx4 per quad); the operand-layout flag stays a per-problem property
         const int fr = 1;
@@ -892,7 +894,7 @@ int point_wgrad(int M, float* ws, int flags, int m_color, const float* d_sdf, fl
         small(B(WS_S_TAU) + (size_t)7 * t256, 256, nullptr, 1, Mp, 256, 1, dW(NET_S, 8), 256, nullptr, 1, fr);
         if (int e = launch_group(g, n, sm, ns, x3 ? KID_WGRAD_S_X3 : KID_WGRAD_S, M, det, x3, st)) return e;
     }
-    if (flags & PF_COLOR) {
+    if ((flags & PF_COLOR) && (net_mask & 4)) {
         n = 0;
         add(B(WS_C_IN), 128, B(WS_C_Y), 256, Mc, 93, 256, dW(NET_C, 0), 349, dB(NET_C, 0), 1);
         add(B(WS_FEAT), 256, B(WS_C_Y), 256, Mc, 256, 256, dW(NET_C, 0) + 93, 349, nullptr, 1);

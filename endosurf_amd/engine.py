@@ -59,6 +59,9 @@ class Engine:
         self._arena, self._arena_off, self._arena_on = None, 0, False
         self._ones1 = None
         self._rng_calls = 0
+        # set by a data-parallel Trainer with overlap_allreduce: called as hook(stage, dweff) behind each weight-gradient launch of a step
+        self.wgrad_stage_hook = None
+        self._grad_pipeline = None          # state of a pipelined data-parallel step (trainer.Trainer._train_step_pipelined)
 
     def st(self):
         """torch's current HIP stream ON THIS ENGINE'S DEVICE.  The library launches on the current HIP device, so the caller must
@@ -142,6 +145,11 @@ class Engine:
             check(self.lib.es_zero(ptr(weff), 4 * weff.numel(), self.st()), "es_zero")
         check(self.lib.es_weightnorm_pack(ptr(flat_params), ptr(weff), ptr(packed), int(use_deform), self.st()), "es_weightnorm_pack")
         return weff, packed
+
+    def weightnorm_backward_layers(self, flat_params, dweff, dparams, first_layer: int, n_layers: int):
+        """Layers [first_layer, first_layer + n_layers) of the 27 (9 * network + layer) into their slices of ``dparams``."""
+        check(self.lib.es_weightnorm_backward_layers(ptr(flat_params), ptr(dweff), ptr(dparams), int(first_layer), int(n_layers), self.st()),
+              "es_weightnorm_backward_layers")
 
     def weightnorm_backward(self, flat_params, dweff, use_deform: bool):
         dparams = self.zeros(self.n_param)
@@ -436,9 +444,10 @@ def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, fp32_o
 Engine.point_forward = _point_forward
 
 
-def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, dweff=None):
+def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, dweff=None, staged: bool = False):
     """Adjoints of (sdf [M,1], g_o [M,3], rgb [M,3]) -> gradient w.r.t. the effective-weight buffer (accumulated into
-    ``dweff`` if given)."""
+    ``dweff`` if given).  ``staged``: this call produces the WHOLE gradient of a step (not one chunk of several), so
+    ``engine.wgrad_stage_hook(stage, dweff)`` -- if set -- may be called behind every network's weight-gradient launch."""
     M = ctx.M
     z = lambda g, w: (g.detach().to(torch.float32).contiguous() if g is not None else self.zeros(M, w))
     d_sdf, d_go = z(d_sdf, 1), z(d_go, 3)
@@ -455,6 +464,17 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, 
               "es_point_backward_x3")
         return dweff
     flags = ctx.flags | (_lib.PF_X3 if self.split_precision else 0)      # opt-in: weight-gradient GEMMs in split precision
+    hook = self.wgrad_stage_hook if staged else None
+    if hook is not None:
+        # the same launches in four calls, with the caller's hook between them: a data-parallel trainer starts the all-reduce of a
+        # network's gradient while the next network's weight-gradient launch runs (Trainer(overlap_allreduce=True))
+        for stage in (_lib.BWD_CHAINS, _lib.BWD_WGRAD_DEFORM, _lib.BWD_WGRAD_SDF, _lib.BWD_WGRAD_COLOR):
+            check(self.lib.es_point_backward_stages(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
+                                                    ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), stage, self.st()),
+                  "es_point_backward_stages")
+            if stage != _lib.BWD_CHAINS:
+                hook(stage, dweff)
+        return dweff
     check(self.lib.es_point_backward_det(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), flags, ctx.m_color, ptr(d_sdf), ptr(d_go),
                                          ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()), "es_point_backward")
     return dweff

@@ -424,7 +424,15 @@ class _PackFn(torch.autograd.Function):
             model._pack_cache = None
         if dweff is None:
             return (None, None, *[None for _ in ctx.slots])
-        dflat = ctx.eng.weightnorm_backward(ctx.flat, dweff.contiguous(), ctx.use_deform)
+        pipe = getattr(ctx.eng, "_grad_pipeline", None)
+        if pipe is not None and pipe.get("dflat") is not None and pipe.get("dweff_ptr") == dweff.data_ptr():
+            # a pipelined data-parallel step (trainer.Trainer overlap_allreduce): the hooks behind the weight-gradient launches have
+            # already written (and are all-reducing) the finished layers' slices; the rest -- whatever the hooks left -- is done here
+            dflat = pipe["dflat"]
+            for first, n in pipe["remaining"]:
+                ctx.eng.weightnorm_backward_layers(ctx.flat, dweff, dflat, first, n)
+        else:
+            dflat = ctx.eng.weightnorm_backward(ctx.flat, dweff.contiguous(), ctx.use_deform)
         if model is not None:
             model._flat_grad = dflat          # the parameters' .grad are views of this buffer (used by trainer.FlatAdam)
         return (None, None, *[dflat[off:off + n].view(shape) for off, n, shape in ctx.slots])
@@ -585,7 +593,7 @@ class _RenderFn(torch.autograd.Function):
                                         g_wmax=sl(g_wmax, i, j), g_gradients_o=sl(g_go, i, j), d_invs_acc=d_invs_acc, n_aux=ctx.n_aux,
                                         g_aux_sdf=opt(g_aux_sdf), g_aux_go=opt(g_aux_go))
             d_sdf, d_go = bw["d_sdf"].view(-1, 1), bw["d_go"]
-            dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"], dweff=dweff)
+            dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, bw["d_rgb"], dweff=dweff, staged=not ctx.chunk_rays)
             del pctx
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852): d var = d inv_s * 10 exp(10 var) inside the clip range
         dvar = eng.variance_terms(var, d_invs_acc=d_invs_acc).reshape(ctx.variance.shape)

@@ -370,7 +370,8 @@ class Trainer:
 
     def __init__(self, renderer, lr: float = 5e-4, n_iter: int = 100000, warm_up_end: int = 5000, lr_alpha: float = 0.05,
                  loss_weights=LOSS_WEIGHTS, surf_neig_rad: float = 0.1, data_parallel: bool = False, fused: bool = True,
-                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False, exact_denominators: bool = False, group=None):
+                 schedule: str = None, flat_adam: bool = True, force_collective: bool = False, exact_denominators: bool = False, group=None,
+                 overlap_allreduce: bool = False):
         self.renderer = renderer
         self.group = group                                  # torch.distributed process group of the data-parallel ranks (None: the default group)
         self.force_collective = bool(force_collective)      # issue the gradient all-reduce even at world size 1 (RCCL smoke test)
@@ -395,6 +396,12 @@ class Trainer:
         # N x B rays (default: standard DDP semantics, per-rank ratios averaged)
         self.exact_denominators = bool(exact_denominators)
         self.allreduce_events = None        # a list: train_step appends a HIP-event pair around its gradient all-reduce
+        # OPT-IN (data parallel, eager steps): the gradient all-reduce as a pipeline of buckets -- a bucket's weight-norm backward and its
+        # all-reduce are issued on a side stream as soon as the weight-gradient launch that completes it is behind the main stream
+        # (_pipeline_hook).  Same sums, same update; no multi-GPU box has measured it yet, so the default stays one bucket.
+        self.overlap_allreduce = bool(overlap_allreduce)
+        self._ar_stream = None
+        self.pipelined_steps = 0            # steps whose gradient really went through the bucket pipeline (not its one-bucket fallback)
         if self.exact_denominators:
             if schedule != "fused":
                 raise ValueError("exact_denominators needs the fused schedule")
@@ -541,7 +548,81 @@ class Trainer:
             eng.arena_end()
         return loss, terms, ret
 
+    # ---- pipelined gradient all-reduce (opt-in) -----------------------------------------------------------------------------------
+    def _bucket_plan(self):
+        """Flat-buffer ranges and weight-norm layer ranges (index = 9 * network + layer) of the buckets.  The weight-gradient launches
+        run deform -> sdf -> colour, and the deformation network's LAST layer is finished by slices riding in the other two launches:
+          A  deform layers 0..7   complete behind the deform launch   (side stream, under the sdf + colour launches)
+          B  sdf                  complete behind the sdf launch      (side stream, under the colour launch)
+          C  deform layer 8, colour, variance                         (main stream, after the backward: exposed)"""
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            from . import params as P
+            m = self.renderer.model
+            off = lambda ni, l: int(m._layout[f"{P.NET_NAMES[ni]}.net.{l}.bias"][0])
+            n_param = int(self.renderer.engine.n_param)
+            deform = bool(m.use_deform)
+            plan = self._plan = dict(
+                A=((0, 8), (off(0, 0), off(0, 8))) if deform else None,
+                B=((9, 9), (off(1, 0), off(2, 0))),
+                remaining=([(8, 1)] if deform else []) + [(18, 9)],
+                C=([(off(0, 8), off(1, 0))] if deform else []) + [(off(2, 0), n_param)])
+        return plan
+
+    def _pipeline_hook(self, stage, dweff):
+        """Called by Engine.point_backward behind every weight-gradient launch of the step (main stream)."""
+        from . import _lib
+        from .parallel import allreduce_flat
+        eng = self.renderer.engine
+        pipe = eng._grad_pipeline
+        plan = self._bucket_plan()
+        if pipe["dflat"] is None:
+            pipe["dflat"], pipe["dweff_ptr"], pipe["remaining"] = eng.zeros(eng.n_param), dweff.data_ptr(), plan["remaining"]
+        job = plan["A"] if stage == _lib.BWD_WGRAD_DEFORM else (plan["B"] if stage == _lib.BWD_WGRAD_SDF else None)
+        if job is None:
+            return
+        (first, n), (a, b) = job
+        main = torch.cuda.current_stream(eng.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self._ar_stream):
+            self._ar_stream.wait_event(ev)
+            eng.weightnorm_backward_layers(self.renderer.model._flat, dweff, pipe["dflat"], first, n)
+            allreduce_flat(pipe["dflat"][a:b], group=self.group, force=self.force_collective)
+
+    def _train_step_pipelined(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        from .parallel import allreduce_flat
+        eng = self.renderer.engine
+        if self._ar_stream is None:
+            self._ar_stream = torch.cuda.Stream(device=eng.device)
+        eng._grad_pipeline = dict(dflat=None, dweff_ptr=None, remaining=None)
+        eng.wgrad_stage_hook = self._pipeline_hook
+        try:
+            loss, terms, ret = self._step_body(batch, global_step, u_perturb, u_neigh)
+        finally:
+            eng.wgrad_stage_hook = None
+            pipe, eng._grad_pipeline = eng._grad_pipeline, None
+        g = self.optimizer.flat_grad(include_variance=True)
+        world = 1
+        if pipe["dflat"] is not None and g.data_ptr() == pipe["dflat"].data_ptr():
+            ev = self.allreduce_events
+            if ev is not None:
+                ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                ev[-1][0].record()
+            for a, b in self._bucket_plan()["C"]:
+                world = allreduce_flat(g[a:b], group=self.group, force=self.force_collective)
+            torch.cuda.current_stream(eng.device).wait_stream(self._ar_stream)
+            if ev is not None:
+                ev[-1][1].record()
+            self.pipelined_steps += 1
+        else:       # the step did not go through the staged backward (chunked render, split-precision chain ...): one bucket
+            world = allreduce_flat(g, group=self.group, force=self.force_collective)
+        self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
+        return loss.detach(), terms, ret
+
     def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
+        if self.overlap_allreduce and self.data_parallel and isinstance(self.optimizer, FlatAdam):
+            return self._train_step_pipelined(batch, global_step, u_perturb, u_neigh)
         loss, terms, ret = self._step_body(batch, global_step, u_perturb, u_neigh)
         if isinstance(self.optimizer, FlatAdam):
             if self.data_parallel:       # ONE all-reduce (sum) of the flat gradient bucket; the 1/world scale rides in the update

@@ -80,6 +80,9 @@ def test_bench_eight_ranks_one_gpu_cold_run_kit():
     assert "error" not in gp and gp["ms_per_step"] > 0 and gp["use_graph"] == (gp["host_bound"] and gp["ms_per_step"] < gp["eager_ms_per_step"]), gp
     assert d["config"]["whole_step_hipgraph"] == gp["use_graph"]
     assert d["allreduce_ms"] > 0 and d["collective_proof"]["allreduce_exposed_ms"] > 0
+    om = d["collective_proof"]["allreduce_other_mode"]          # a few steps of the pipelined all-reduce next to the one-bucket headline
+    assert om["overlap_allreduce"] is True and om["pipelined_steps"] >= 8 and om["ms_per_step"] > 0, om
+    assert d["collective_proof"]["replicas_bit_identical"] is True
 
 
 def test_bench_self_launches_without_torchrun():
@@ -177,6 +180,60 @@ torch.distributed.destroy_process_group()
     assert d["moved"] > 1e-4, d
 
 
+@pytest.mark.parametrize("use_deform", [True, False])
+def test_pipelined_allreduce_equals_the_single_bucket(use_deform):
+    """Trainer(overlap_allreduce=True): the gradient all-reduce as three buckets, two of them issued on a side stream behind the
+    weight-gradient launch that completes them (es_point_backward_stages + es_weightnorm_backward_layers).  Two ranks with different
+    batches (gloo, one GPU), deterministic reductions: after three steps the parameters equal those of the default single-bucket step
+    bit for bit, and the replicas are identical."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["ES_REPO"]); sys.path.insert(0, os.path.join(os.environ["ES_REPO"], "tests"))
+import torch
+from endosurf_amd import parallel
+from endosurf_amd.trainer import Trainer, SyntheticScene
+from gpu_util import renderer_for
+rank, world, local = parallel.init_distributed("gloo")
+torch.cuda.set_device(0)
+use_deform = os.environ["ES_USE_DEFORM"] == "1"
+def run(overlap):
+    torch.manual_seed(0)
+    r = renderer_for(5, "trained", use_deform)
+    r.engine.deterministic = True
+    tr = Trainer(r, lr=1e-3, data_parallel=True, overlap_allreduce=overlap)
+    parallel.broadcast_parameters(tr.params)
+    sc = SyntheticScene("cuda", seed=100 + rank)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(50 + rank)
+    for it in range(3):
+        b = sc.batch(256)
+        u, un = torch.rand(256, 1, device="cuda", generator=gen), torch.rand(256, 3, device="cuda", generator=gen)
+        tr.update_learning_rate(7000 + it)
+        tr.train_step(b, 20000 + it, u_perturb=u, u_neigh=un)
+    torch.cuda.synchronize()
+    assert tr.pipelined_steps == (3 if overlap else 0), tr.pipelined_steps
+    return r.model._flat.detach().clone()
+a = run(False)
+b = run(True)
+both = [torch.zeros_like(b) for _ in range(world)]
+torch.distributed.all_gather(both, b)
+if rank == 0:
+    print(json.dumps(dict(overlap_vs_single=int((a != b).sum()), replicas=int((both[0] != both[1]).sum()),
+                          moved=float((a - renderer_for(5, "trained", use_deform).model._flat).abs().max()))))
+torch.distributed.destroy_process_group()
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "w.py")
+        open(script, "w").write(code)
+        env = dict(os.environ, ES_REPO=REPO, ES_USE_DEFORM="1" if use_deform else "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), script]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["overlap_vs_single"] == 0 and d["replicas"] == 0 and d["moved"] > 1e-4, d
+
+
 def test_rccl_world1_trainer_allreduce():
     """The RCCL path itself, on one GPU: backend "nccl" (= RCCL on ROCm) at world size 1, parameter broadcast, and a data-parallel
     Trainer whose flat 6.6 MB gradient bucket goes THROUGH the all-reduce (``force_collective``): librccl loads, the communicator
@@ -195,11 +252,11 @@ os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1)
 assert dist.get_backend() == "nccl"
-def run(dp):
+def run(dp, overlap=False):
     torch.manual_seed(0)                     # the stratified jitter / neighbour offsets are drawn with torch.rand on the device
     r = renderer_for(5, "trained", True)
     r.engine.deterministic = True
-    tr = Trainer(r, lr=1e-3, data_parallel=dp, force_collective=dp)
+    tr = Trainer(r, lr=1e-3, data_parallel=dp, force_collective=dp, overlap_allreduce=overlap)
     if dp:
         parallel.broadcast_parameters(tr.params)
     sc = SyntheticScene("cuda", seed=100)
@@ -212,7 +269,9 @@ g = torch.full((1654951,), 2.0, device="cuda")
 w = parallel.allreduce_flat(g, force=True)
 torch.cuda.synchronize()
 b = run(False)
-print(json.dumps(dict(world=w, bucket_ok=bool((g == 2.0).all()), maxdiff=float((a - b).abs().max()), finite=bool(torch.isfinite(a).all()))))
+c = run(True, overlap=True)                  # the bucket pipeline: its side-stream all-reduces go through RCCL as well
+print(json.dumps(dict(world=w, bucket_ok=bool((g == 2.0).all()), maxdiff=float((a - b).abs().max()), finite=bool(torch.isfinite(a).all()),
+                      maxdiff_pipelined=float((c - b).abs().max()))))
 dist.destroy_process_group()
 '''
     import tempfile
@@ -225,7 +284,7 @@ dist.destroy_process_group()
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["world"] == 1 and d["bucket_ok"] and d["finite"], d
-    assert d["maxdiff"] == 0.0, d
+    assert d["maxdiff"] == 0.0 and d["maxdiff_pipelined"] == 0.0, d
 
 
 def test_bench_rccl_world1_line():
