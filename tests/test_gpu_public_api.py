@@ -297,3 +297,21 @@ def test_color_network_forward_on_explicit_inputs(name):
     rgb2 = r.model.color_network(x.reshape(4, 50, 3), n.reshape(4, 50, 3), 2.0 * d.reshape(4, 50, 3), feat.reshape(4, 50, 256))
     assert tuple(rgb2.shape) == (200, 3) and float((rgb2 - rgb).abs().max()) > 1e-4
     assert r.model.color_network(x[:0], n[:0], d[:0], feat[:0]).shape == (0, 3)
+
+
+def test_point_adjoint_keeps_the_callers_shape_and_dtype():
+    """The adjoint of the query points comes back in the caller's tensor: any leading shape, float64 points, a scalar time."""
+    r = renderer_for(13, "trained", True)
+    x = (torch.rand(4, 5, 3, device="cuda", dtype=torch.float64) - 0.5).requires_grad_(True)
+    g = r.model.get_sdf_grad_from_observed_space(x, torch.tensor(0.3, device="cuda"))
+    assert tuple(g.shape) == (20, 3) and g.requires_grad
+    (g ** 2).sum().backward()
+    assert x.grad is not None and tuple(x.grad.shape) == (4, 5, 3) and x.grad.dtype == torch.float64
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+    # twice through the same node (retain_graph): the consumed workspace is re-evaluated, the result is the same
+    x2 = x.detach().clone().requires_grad_(True)
+    g2 = r.model.get_sdf_grad_from_observed_space(x2, torch.tensor(0.3, device="cuda"))
+    l2 = (g2 ** 2).sum()
+    (a,) = torch.autograd.grad(l2, x2, retain_graph=True)
+    (b,) = torch.autograd.grad(l2, x2)
+    assert torch.allclose(a, x.grad, rtol=1e-5, atol=1e-7) and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
