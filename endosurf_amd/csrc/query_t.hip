@@ -95,6 +95,42 @@ __device__ __forceinline__ void gemm_seg_t(f32x16 (&acc)[2][PTC], const float* X
         }
     };
 
+    if constexpr ((DBG & 128) != 0 && KG % 4 == 0 && KG >= 8) {
+        // dev experiment: the SAME 32 weight registers as a ring of four one-group sets; the two loads of group g + 3 are issued one after
+        // the 4th and one after the 12th MFMA of group g -- an even trickle (one load per 8 MFMAs, three groups = 3 072 cycles ahead)
+        // instead of bursts of four loads once per 32 MFMAs
+        float4 w[4][2];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) w[u][mi] = wl[(size_t)((mt0 + mi) * KG + u) * 64];
+        loadX(x0, 0);
+#pragma unroll 1
+        for (int g0 = 0; g0 < KG; g0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u;
+                float4(&xc)[PTC] = (u & 1) ? x1 : x0;
+                float4(&xn)[PTC] = (u & 1) ? x0 : x1;
+                if (g + 1 < KG) loadX(xn, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int pi = 0; pi < PTC; ++pi)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            acc[mi][pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(w[u][mi], j), f4c(xc[pi], j), acc[mi][pi], 0, 0, 0);
+                    if (j == 0 || j == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + 3 < KG) w[(u + 3) & 3][j >> 1] = wl[(size_t)((mt0 + (j >> 1)) * KG + g + 3) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        return;
+    }
     loadW(w0, 0);
     loadX(x0, 0);
     if constexpr (KG > 2 * PF) {
@@ -393,6 +429,12 @@ int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, flo
             allow_big_lds(k_query_sdf_t<true, false, 8>, QT_LDS_BYTES); allow_big_lds(k_query_sdf_t<true, false, 16>, QT_LDS_BYTES);
             allow_big_lds(k_query_sdf_t<true, false, 30>, QT_LDS_BYTES); allow_big_lds(k_query_sdf_t<true, false, 12>, QT_LDS_BYTES);
             attr = true;
+        }
+        if (dbg == 128) {
+            static bool a128 = false;
+            if (!a128) { allow_big_lds(k_query_sdf_t<true, false, 128>, QT_LDS_BYTES); a128 = true; }
+            hipLaunchKernelGGL((k_query_sdf_t<true, false, 128>), grid, block, QT_LDS_BYTES, st, src, tb, pk, weff, sdf_out, ld_out, ray_done, 0);
+            return hip_last("query_sdf_t");
         }
         if (dbg == 64) {
             static bool a64 = false;
