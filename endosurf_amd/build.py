@@ -41,13 +41,20 @@ def _newest_header_mtime():
 def _compile(src: str, force: bool, extra):
     obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
+    # an object is reused only if it was built with the SAME code-generation flags (-D...): a dev build (-DES_DEV_SWITCHES) followed by
+    # a plain build must not link dev objects into the product library
+    codegen = " ".join([*FLAGS, *[e for e in extra if not e.startswith("-R")]])
+    stamp = obj + ".flags"
+    same_flags = os.path.exists(stamp) and open(stamp).read() == codegen
+    if (not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(srcp)
             and os.path.getmtime(obj) > _newest_header_mtime()):
         return obj, False, ""
     cmd = [hipcc(), *FLAGS, *extra, "-c", srcp, "-o", obj]
     p = subprocess.run(cmd, capture_output=True, text=True)
     if p.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{p.stdout}\n{p.stderr}")
+    with open(stamp, "w") as f:
+        f.write(codegen)
     return obj, True, p.stderr
 
 
