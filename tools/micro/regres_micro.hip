@@ -22,7 +22,9 @@ __device__ __forceinline__ float softplus100(float z) {
     return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.f + e), fmaxf(z, 0.f));
 }
 
-// MODE bits: 1 = weight ring refilled by direct loads (else the ring is static), 2 = barriers, 4 = softplus (else ReLU), 8 = no activation at all
+// MODE bits: 1 = weight ring refilled by direct loads (else the ring is static), 2 = barriers, 4 = softplus (else ReLU), 8 = no activation at all,
+// 16 = only ONE of a wave's two pieces per k-group is loaded (half the instructions, half the bytes), 32 = both pieces, but always the
+// SAME 2 KB of the packed buffer (same instruction count, the bytes come from a hot cache line set)
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_regres(const float4* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, int layers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -41,9 +43,9 @@ __global__ __launch_bounds__(256, 1) void k_regres(const float4* __restrict__ Wp
     auto dma = [&](long G) {      // this wave's 2 of the 8 1-KB pieces of k-group G
         if (!(MODE & 1) || G >= n_groups) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ((MODE & 16) ? 1 : 2); ++i) {
             const int piece = 2 * wave + i;
-            const float4* src = gsrc + (G * 8 + piece) * 64;
+            const float4* src = gsrc + (((MODE & 32) ? 0 : G) * 8 + piece) * 64;
             unsigned char* dst = lds + ((G & (RING - 1)) * 8 + piece) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -136,6 +138,8 @@ int main() {
     printf("register-resident fp32 chain, 128 points per workgroup (1 wave per SIMD), %d blocks x %d layers of 256 x 256\n", blocks, layers);
     run<8 + 2>("MFMAs + fragment reads from a static ring + one barrier per pair of k-groups", W, bias, out, blocks, layers);
     run<8 + 2 + 1>("+ weight ring refilled by direct loads (256 KB per layer and workgroup)", W, bias, out, blocks, layers);
+    run<8 + 2 + 1 + 16>("  ... one piece per wave and k-group instead of two (half instructions, half bytes)", W, bias, out, blocks, layers);
+    run<8 + 2 + 1 + 32>("  ... two pieces, always the same 2 KB (same instructions, hot lines)", W, bias, out, blocks, layers);
     run<2 + 1>("+ bias + ReLU, lazily on the operand registers", W, bias, out, blocks, layers);
     run<4 + 2 + 1>("+ bias + softplus(100) instead", W, bias, out, blocks, layers);
     run<4 + 2 + 1>("same, 64 layers", W, bias, out, blocks, 64);
