@@ -533,6 +533,142 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+class ReferenceLoop:
+    """The reference trainer's OWN training step against the drop-in renderer -- what a maintainer gets from INTEGRATION.md's import swap
+    and nothing else: ``init_optimizer`` (trainer_endosurf.py:60-72: ``torch.optim.Adam(params=grad_vars, lr=lr_init)`` over the 82
+    parameter tensors, torch's defaults), ``train_step`` (:94-104: zero_grad -> compute_loss -> backward -> step -> ``loss.item()``),
+    ``compute_loss`` (:106-181: ``renderer(rays)``, torch loss arithmetic with ``F.l1_loss``, ``errorondepth``,
+    ``surface_neighbour_error`` as three separate calls) and ``update_learning_rate`` (:183-203).  Nothing of endosurf_amd.trainer is used
+    except the synthetic batch generator (the stand-in for ``Dataset.get_train_batch_data_by_index``).
+    ``logging``: also the reference's per-step host traffic: ``cal_psnr`` on numpy copies (src/trainer/utils.py:340-353, three D2H
+    copies) and the ``writer.add_scalar(tensor)`` calls of :165-179 (each one a D2H copy of a 0-d tensor = a host sync)."""
+
+    W = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)      # base_pull.yml:23-29
+
+    def __init__(self, ctx, logging=False, config_id=2):
+        import torch
+        from endosurf_amd import EndoSurfRenderer
+        from endosurf_amd.trainer import SyntheticScene
+        cfg = CONFIGS[config_id]
+        torch.manual_seed(0)
+        self.cfg, self.logging = cfg, bool(logging)
+        self.renderer = EndoSurfRenderer(render_cfg(cfg), dict(NET_CFG, use_deform=cfg["use_deform"]), device=ctx.dev)
+        train_params = self.renderer.get_train_params()
+        grad_vars = []
+        for key in train_params.keys():
+            grad_vars += train_params[key]
+        self.optimizer = torch.optim.Adam(params=grad_vars, lr=5e-4)
+        self.lr_init, self.n_iter = 5e-4, 100000
+        scene = SyntheticScene(ctx.dev, seed=1234 + ctx.rank)
+        self.batches = [scene.batch(cfg["rays"]) for _ in range(4)]
+        self.t_issue = []          # per step: seconds from the step's first call to just before loss.item()
+        self.scalars = 0
+
+    def _log(self, t):
+        """``SummaryWriter.add_scalar(tag, tensor)``: the value comes to the host (make_np: ``.detach().cpu().numpy()``)."""
+        self.scalars += 1
+        return t.detach().cpu().numpy()
+
+    def compute_loss(self, data, global_step):
+        import numpy as np
+        import torch
+        import torch.nn.functional as F
+        r, w = self.renderer, self.W
+        rays, color_gt, depth_gt, mask_gt, color_mask_gt = data["rays"], data["color"], data["depth"], data["mask"], data["color_mask"]
+        ret = r(rays, iter_step=global_step)
+        color_pred = ret["color_map"]
+        color_error = (color_pred - color_gt) * color_mask_gt
+        color_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / (color_mask_gt.sum() + 1e-10)
+        sdf_loss, angle_loss, valid_depth_region = r.errorondepth(rays, d_gt=depth_gt, mask=mask_gt, iter_step=global_step)
+        depth_pred = ret["depth_map"]
+        depth_error = (depth_pred - depth_gt) * valid_depth_region * mask_gt
+        depth_loss = F.l1_loss(depth_error, torch.zeros_like(depth_error), reduction="sum") / ((valid_depth_region * mask_gt).sum() + 1e-10)
+        eikonal_loss = ret["gradient_o_error"]
+        surf_neig_loss = r.surface_neighbour_error(rays=rays, mask=mask_gt, iter_step=global_step, neighbour_rad=0.1)
+        loss = (color_loss * w["color"] + depth_loss * w["depth"] + sdf_loss * w["sdf"] + angle_loss * w["angle"]
+                + eikonal_loss * w["eikonal"] + w["surf_neig"] * surf_neig_loss)
+        if self.logging:          # (these host reads sit BEFORE the backward, as in the reference: the host waits for the forward here)
+            a, b, m = (t.detach().cpu().numpy() for t in (color_pred, color_gt, color_mask_gt))          # cal_psnr -> tensor2array
+            _psnr = 20.0 * np.log10(1.0 / (((a - b) ** 2 * m).sum() / ((np.sum(m) + 1e-10) * 3.0)) ** 0.5)
+            for t in (color_loss, sdf_loss, angle_loss, depth_loss, eikonal_loss, surf_neig_loss, loss, ret["s_val"].mean(),
+                      (ret["cdf"][:, :1] * mask_gt).sum() / (mask_gt.sum() + 1e-10), (ret["weight_max"] * mask_gt).sum() / (mask_gt.sum() + 1e-10)):
+                self._log(t)
+        return loss
+
+    def update_learning_rate(self, global_step, warm_up_end=5000, alpha=0.05):
+        import numpy as np
+        if global_step < warm_up_end:
+            f = global_step / warm_up_end
+        else:
+            f = (np.cos(np.pi * (global_step - warm_up_end) / (self.n_iter - warm_up_end)) + 1.0) * 0.5 * (1 - alpha) + alpha
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.lr_init * f
+
+    def train_step(self, i):
+        """One iteration of the reference's main loop (trainer_basic.py:86-105): train_step + update_learning_rate; -> loss (host float)."""
+        data = self.batches[i % len(self.batches)]
+        t0 = time.perf_counter()
+        self.optimizer.zero_grad()
+        loss = self.compute_loss(data, i + 1)
+        loss.backward()
+        self.optimizer.step()
+        self.t_issue.append(time.perf_counter() - t0)
+        v = loss.item()
+        self.update_learning_rate(i + 1)
+        return v
+
+    def measure(self, warmup, steps, timing_steps=3):
+        import torch
+        from endosurf_amd import _lib
+        eng = self.renderer.engine
+        for i in range(warmup):
+            self.train_step(i)
+        torch.cuda.synchronize()
+        self.t_issue, self.scalars = [], 0
+        calls0 = _lib.calls
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.train_step(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        calls = (_lib.calls - calls0) / steps
+        # (a logging step blocks on its host reads in the middle: "time to enqueue" is only defined for the plain step)
+        issue = None if self.logging else sorted(self.t_issue)[len(self.t_issue) // 2] * 1e3
+        syncs = 1 + (self.scalars // steps + 3 if self.logging else 0)
+        timing = kernel_timing(eng, self.train_step, warmup + steps, timing_steps, self.cfg["use_deform"])
+        per = timing.get("per_step_ms") or {}
+        opt = self.optimizer
+        return dict(ms_per_step=dt / steps * 1e3, value=self.cfg["rays"] * steps / dt, unit="rays/s", steps=steps, warmup=warmup,
+                    host_issue_ms=issue, host_syncs_per_step=syncs, library_calls_per_step=calls,
+                    sum_timed_kernel_ms=sum(per.values()) if per else None, kernel_ms_per_step=per or None,
+                    optimizer="torch.optim.Adam(params=grad_vars, lr) over %d tensors, torch defaults (%s)" % (
+                        len(opt.param_groups[0]["params"]),
+                        "foreach" if opt.param_groups[0].get("foreach") in (None, True) and not opt.param_groups[0].get("fused") else "fused"))
+
+
+def reference_call_sequence(ctx, args, steps=None):
+    """extras.reference_call_sequence: the reference trainer's own loop through the drop-in, config 2, same synthetic
+    batches as the headline -- without and with the reference's per-step logging traffic."""
+    import gc
+    import torch
+    short = args.steps < 10
+    steps = steps or (4 if short else 20)
+    out = {}
+    for name, logging in (("plain", False), ("with_reference_logging", True)):
+        loop = ReferenceLoop(ctx, logging=logging)
+        out[name] = loop.measure(3, steps, timing_steps=2 if short else 3)
+        loop = None
+        gc.collect()
+        torch.cuda.empty_cache()
+    out["what"] = ("the reference trainer's own step (trainer_endosurf.py:60-72, 94-104, 106-181, 183-203) with "
+                   "src.renderer.endosurf.EndoSurfRenderer replaced by endosurf_amd.EndoSurfRenderer and nothing else: renderer(rays) -> "
+                   "errorondepth -> surface_neighbour_error as three calls, torch loss arithmetic, loss.backward(), torch.optim.Adam.step() "
+                   "over the parameter tensors, loss.item(); 'with_reference_logging' adds cal_psnr's three D2H copies and the ten "
+                   "add_scalar(tensor) host syncs of :165-179.  ms_per_step is wall time per iteration (every iteration ends in a host "
+                   "sync, so host issue and GPU work of consecutive steps do not overlap)")
+    return out
+
+
 def collective_proof(ctx, wl, dt_local):
     """What the collective itself saw (N > 1, or the forced one-rank RCCL group): an all-reduce of ones, every rank's own ms per step,
     and the time of the step's ONE data-path collective (the all-reduce of the flat gradient bucket) from HIP events around it."""
@@ -617,6 +753,11 @@ def run_extras(ctx, args, partial):
         plan = [p for p in plan if p[0] in ("cfg4", "cfg5_frame")]
         partial["skipped_at_n_gt_1"] = "forward, split_precision_train, cfg3: single-GPU lines (reported by the N = 1 run)"
     ok = True
+    if ctx.world == 1:
+        try:
+            partial["reference_call_sequence"] = reference_call_sequence(ctx, args)
+        except Exception as e:
+            partial["reference_call_sequence"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:500]))
     for name, kw, warm, steps, tsteps in plan:
         if ctx.dist_on:      # a rank that failed an extra must not leave the others waiting inside the next one's collectives
             flag = torch.tensor([1.0 if ok else 0.0], device=ctx.dev)
@@ -658,6 +799,8 @@ def main():
     ap.add_argument("--rays", type=int, default=None, help="override the configuration's rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default=None, choices=["train", "forward", "frame"])
+    ap.add_argument("--refseq-only", choices=["plain", "logging"], default=None,
+                    help="profiling aid: run ONLY the reference trainer's own loop through the drop-in (ReferenceLoop) and print its record")
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
     ap.add_argument("--headline-only", action="store_true",
@@ -714,6 +857,11 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     affinity = (parallel.pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), local_world) if world > 1 and not args.no_pin
                 else dict(pinned=False, reason="one rank" if world == 1 else "--no-pin"))
+
+    if args.refseq_only:
+        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging")
+        print(json.dumps(loop.measure(args.warmup, args.steps)), flush=True)
+        return
 
     # ---- headline ---------------------------------------------------------------------------------------------------------------
     wl = Workload(ctx, args.config, mode=args.mode, split=args.split_precision, rays=args.rays, chunk=args.chunk, graph=args.graph,

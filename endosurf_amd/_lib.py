@@ -78,6 +78,14 @@ PROTOTYPES = {
     "es_point_workspace_floats": (C.c_int64, [_I, _I]),
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
+    "es_point_forward_rows": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _I, _I, _P]),
+    "es_eod_points": (_I, [_P, _P, _I, _P, _P, _P]),
+    "es_sn_points": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
+    "es_eod_loss": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "es_eod_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "es_sn_loss": (_I, [_P, _P, _I, _P, _P]),
+    "es_sn_loss_backward": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "es_copy2": (_I, [_P, _P, C.c_longlong, _P, _P, C.c_longlong, _P]),
     "es_color_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _P]),
     "es_point_vjp": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _P]),
     "es_point_backward_stages": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
@@ -112,7 +120,7 @@ PROTOTYPES = {
     "es_kernel_name": (C.c_char_p, [_I]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
@@ -146,7 +154,12 @@ def load():
     return lib
 
 
+calls = 0          # library calls checked so far (a measurement counter: bench.py reports library calls per step)
+
+
 def check(status: int, what: str = ""):
+    global calls
+    calls += 1
     if status != 0:
         msg = load().es_last_error()
         raise EndoSurfHipError(f"{what or 'libendosurf_hip'} failed (status {status}): {msg.decode() if msg else ''}")

@@ -23,6 +23,17 @@ int variance_terms(const float* variance, const float* d_invs_acc, float* s_val,
 
 int point_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, hipStream_t st,
                   const void* packed_x3 = nullptr);
+int point_forward_rows(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, int row0, int nrows,
+                       hipStream_t st);
+int eod_points(const float* rays, const float* depth_gt, int N, float* x, float* t, hipStream_t st);
+int sn_points(const float* rays, const float* mask, const float* d_i, const float* u, float rad, int N, float* x, float* t, unsigned char* valid,
+              hipStream_t st);
+int eod_loss(const float* rays, const float* pts, const float* mask, const float* sdf, const float* go, int N, float* out, float* inside, hipStream_t st);
+int eod_loss_bwd(const float* rays, const float* inside, const float* sdf, const float* go, const float* out, const float* g_sdf_err,
+                 const float* g_ang_err, int N, float* d_sdf, float* d_go, hipStream_t st);
+int sn_loss(const float* g, const unsigned char* valid, int N, float* out, hipStream_t st);
+int sn_loss_bwd(const float* g, const unsigned char* valid, const float* out, const float* g_loss, int N, float* d_g, hipStream_t st);
+int copy2(float* da, const float* sa, long long na, float* db, const float* sb, long long nb, hipStream_t st);
 int color_forward(const PointSrc& src, const float* packed, const float* weff, float* ws, hipStream_t st);
 int point_vjp(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, hipStream_t st);
 int point_backward_chains(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color,
@@ -249,6 +260,47 @@ int es_point_forward(const es_points* pts, const float* packed, const float* wef
     ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     return point_forward(to_src(pts), packed, weff, ws, flags, m_color, (hipStream_t)stream);
+}
+int es_point_forward_rows(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, int m_color, int row0, int nrows,
+                          void* stream) {
+    if (int e = check_src(pts)) return e;
+    ES_REQUIRE(packed && weff && (ws || pts->M == 0), "null buffer");
+    ES_REQUIRE(!(flags & (ES_PF_X3 | ES_PF_X3_CHAIN)), "es_point_forward_rows: fp32 family only");
+    ES_REQUIRE(!(flags & ES_PF_COLOR) || pts->mode != 0 || pts->dirs, "colour evaluation needs view directions");
+    ES_REQUIRE(row0 >= 0 && nrows >= 0, "es_point_forward_rows: negative row range");
+    if (int e = check_mcolor(pts, flags, m_color)) return e;
+    return point_forward_rows(to_src(pts), packed, weff, ws, flags, m_color, row0, nrows, (hipStream_t)stream);
+}
+int es_eod_points(const float* rays, const float* depth_gt, int N, float* x, float* t, void* stream) {
+    ES_REQUIRE(N >= 0 && (N == 0 || (rays && depth_gt && x && t)), "es_eod_points buffers");
+    return eod_points(rays, depth_gt, N, x, t, (hipStream_t)stream);
+}
+int es_sn_points(const float* rays, const float* mask, const float* d_i, const float* u, float rad, int N, float* x, float* t,
+                 unsigned char* valid, void* stream) {
+    ES_REQUIRE(N >= 0 && (N == 0 || (rays && mask && d_i && u && x && t && valid)), "es_sn_points buffers");
+    return sn_points(rays, mask, d_i, u, rad, N, x, t, valid, (hipStream_t)stream);
+}
+int es_eod_loss(const float* rays, const float* pts, const float* mask, const float* sdf, const float* g_o, int N, float* out, float* inside,
+                void* stream) {
+    ES_REQUIRE(N >= 0 && out && (N == 0 || (rays && pts && mask && sdf && g_o && inside)), "es_eod_loss buffers");
+    return eod_loss(rays, pts, mask, sdf, g_o, N, out, inside, (hipStream_t)stream);
+}
+int es_eod_loss_backward(const float* rays, const float* inside, const float* sdf, const float* g_o, const float* out, const float* g_sdf_err,
+                         const float* g_ang_err, int N, float* d_sdf, float* d_go, void* stream) {
+    ES_REQUIRE(N >= 0 && (N == 0 || (rays && inside && sdf && g_o && out && d_sdf && d_go)), "es_eod_loss_backward buffers");
+    return eod_loss_bwd(rays, inside, sdf, g_o, out, g_sdf_err, g_ang_err, N, d_sdf, d_go, (hipStream_t)stream);
+}
+int es_sn_loss(const float* g, const unsigned char* valid, int N, float* out, void* stream) {
+    ES_REQUIRE(N >= 0 && out && (N == 0 || (g && valid)), "es_sn_loss buffers");
+    return sn_loss(g, valid, N, out, (hipStream_t)stream);
+}
+int es_sn_loss_backward(const float* g, const unsigned char* valid, const float* out, const float* g_loss, int N, float* d_g, void* stream) {
+    ES_REQUIRE(N >= 0 && (N == 0 || (g && valid && out && g_loss && d_g)), "es_sn_loss_backward buffers");
+    return sn_loss_bwd(g, valid, out, g_loss, N, d_g, (hipStream_t)stream);
+}
+int es_copy2(float* da, const float* sa, long long na, float* db, const float* sb, long long nb, void* stream) {
+    ES_REQUIRE(na >= 0 && nb >= 0 && (na == 0 || (da && sa)) && (nb == 0 || (db && sb)), "es_copy2 buffers");
+    return copy2(da, sa, na, db, sb, nb, (hipStream_t)stream);
 }
 int es_point_vjp(const es_points* pts, const float* packed, const float* weff, float* ws, int flags, void* stream) {
     if (int e = check_src(pts)) return e;

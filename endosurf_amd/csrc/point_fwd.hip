@@ -138,6 +138,44 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
 }
 
 
+// Rows [row0, row0 + nrows) of a workspace laid out for ALL of src.M points (ABI v8, es_point_forward_rows): the forward of a workspace
+// that is filled piece by piece.  The reference trainer calls renderer(rays), errorondepth and surface_neighbour_error one after the other
+// (trainer_endosurf.py:130, :140, :155) and back-propagates once: the render's workspace is laid out with room for the colour-less points
+// of the two later calls behind its samples, each call evaluates its own rows when it is made, and ONE es_point_backward over the whole
+// workspace -- with the tail's stages mixed into the main launches (point_bwd.hip) -- replaces three separate backward chains, two of them
+// latency-bound (16 - 32 workgroups) launches at a tile's full latency each.
+//   row0 == 0, nrows == m_color:  the main part (colour points): deform | sdf | colour | vjp over its tiles only
+//   row0 >= m_color:              a piece of the colour-less tail (row0, nrows multiples of 64): deform on half-height tiles | [sdf + vjp]
+// fp32 family only.
+int point_forward_rows(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, int row0, int nrows,
+                       hipStream_t st) {
+    if (src.M <= 0 || nrows <= 0) return ST_OK;
+    FwdArgs a;
+    a.src = src; a.tb = make_tabs(); a.packed = reinterpret_cast<const float4*>(packed); a.weff = weff; a.ws = ws;
+    a.L = ws_layout(src.M, flags); a.flags = flags;
+    a.M_color = (flags & PF_COLOR) ? (m_color > 0 ? m_color : src.M) : 0;
+    const int Mc = a.M_color;
+    const bool deform = flags & PF_DEFORM;
+    if (row0 + nrows > a.L.Mp) return fail(ST_BAD_ARG, "point_forward_rows", "rows beyond the workspace");
+    if (row0 == 0 && nrows == Mc && Mc % 64 == 0) {
+        if (deform) { ScopedTimer tm(KID_DEFORM_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM>(a, 0, 0, Mc / 32, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        { ScopedTimer tm(KID_COLOR_FWD, Mc, st); if (int e = launch_fwd<FB_NONE, FB_COLOR>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        if (deform) { ScopedTimer tm(KID_DEFORM_VJP, Mc, st); if (int e = launch_fwd<FB_NONE, FB_VJP>(a, 0, 0, Mc / TM, 0, st)) return e; }
+        return hip_last("point_forward_rows");
+    }
+    if (row0 < Mc || row0 % 64 != 0 || nrows % 64 != 0)
+        return fail(ST_BAD_ARG, "point_forward_rows", "rows: either the whole colour part [0, m_color) or a 64-aligned piece of the colour-less tail");
+    if (deform) {
+        { ScopedTimer tm(KID_DEFORM_FWD, nrows, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM_HALF>(a, 0, 0, nrows / 16, row0 / 16, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, nrows, st); if (int e = launch_fwd<FB_SDF_VJP, FB_DEFORM>(a, nrows / TM, row0 / TM, 0, 0, st)) return e; }
+    } else {
+        ScopedTimer tm(KID_SDF_FWD, nrows, st);
+        if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, nrows / TM, row0 / TM, st)) return e;
+    }
+    return hip_last("point_forward_rows");
+}
+
 // The VJP sweep of the deformation network on its own, for the covector the caller has written to WS_GC of a workspace that a forward
 // of the SAME points has filled (the sweep reads that forward's ReLU mask words): WS_GO = J^T c, WS_CURV = the encoding-curvature sums
 // against the same adjoint.  Nothing is saved (PF_SAVE is ignored: the forward's saved VJP adjoints stay as they are).

@@ -444,6 +444,16 @@ def _point_forward(self, pts, weff, packed, flags: int, m_color: int = 0, fp32_o
 Engine.point_forward = _point_forward
 
 
+def _point_forward_rows(self, ctx: PointCtx, weff, packed, row0: int, nrows: int):
+    """Rows [row0, row0 + nrows) of a workspace that is filled piece by piece (es_point_forward_rows): the colour part of a render whose
+    workspace has room for the colour-less points of later calls, or one of those calls' pieces of the tail.  fp32 kernels."""
+    check(self.lib.es_point_forward_rows(C.byref(ctx.pts), ptr(packed), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, int(row0), int(nrows),
+                                         self.st()), "es_point_forward_rows")
+
+
+Engine.point_forward_rows = _point_forward_rows
+
+
 def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, dweff=None, staged: bool = False):
     """Adjoints of (sdf [M,1], g_o [M,3], rgb [M,3]) -> gradient w.r.t. the effective-weight buffer (accumulated into
     ``dweff`` if given).  ``staged``: this call produces the WHOLE gradient of a step (not one chunk of several), so

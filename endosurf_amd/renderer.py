@@ -493,6 +493,120 @@ class _PointEvalFn(torch.autograd.Function):
         return dweff, None, None, None, None, xbar
 
 
+class _Tail:
+    """Room behind a grad-enabled render's samples for the colour-less points of the calls that FOLLOW it in the reference trainer's step
+    (``renderer(rays)`` -> ``errorondepth`` -> ``surface_neighbour_error``, trainer_endosurf.py:130, :140, :155).  The render lays its point
+    workspace out for P + cap rows and evaluates the first P; each later grad-enabled point evaluation writes its points into the next free
+    rows of (aux_x, aux_t), evaluates exactly those rows (es_point_forward_rows) and deposits its adjoints in (g_sdf, g_go) when autograd
+    reaches it; the render's backward -- which autograd runs after them, see ``_TailEvalFn`` -- then back-propagates the whole workspace in
+    ONE chain of launches with the tail's stages mixed into the main ones, exactly as the fused training step does.  The three separate
+    backward chains this replaces cost 2.1 ms of a 19.6 ms step (two of them run 16 - 32 workgroups at a tile's full latency per launch).
+
+    ``cap`` is learnt: the rows the previous step asked for (EndoSurfRenderer._aux_demand); rows nobody claimed are evaluated (at whatever
+    finite points the buffer holds, with zero adjoints) before the backward, so every row of the workspace is defined."""
+
+    def __init__(self, eng: Engine, P_: int, cap: int):
+        self.P, self.cap, self.used = int(P_), int(cap), 0
+        buf = eng.zeros(8 * cap)                      # one allocation, one fill: points (x | t) and adjoints (g_sdf | g_go)
+        self.aux_x, self.aux_t = buf[:3 * cap].view(cap, 3), buf[3 * cap:4 * cap]
+        self.g_sdf, self.g_go = buf[4 * cap:5 * cap].view(cap, 1), buf[5 * cap:].view(cap, 3)
+        self.pctx, self.weff, self.flags = None, None, 0
+
+    def room(self, m64: int, weff, flags: int) -> bool:
+        return self.pctx is not None and self.weff is weff and self.flags == flags and self.used + m64 <= self.cap
+
+
+class _TailEvalFn(torch.autograd.Function):
+    """(sdf [m,1], g_o [m,3]) of ``m`` colour-less points evaluated into rows [off, off + m) of a live render's tail (``_Tail``).
+
+    The only differentiable input is the render's ``token`` output: it makes the render node a dependency of this one, so autograd runs
+    this backward -- which merely deposits the adjoints -- BEFORE the render's (even when nothing else of the render is used in the
+    loss), and the render's backward carries them to the weights."""
+
+    @staticmethod
+    def forward(ctx, token, tail: _Tail, eng: Engine, off: int, m: int):
+        pctx = tail.pctx
+        r0 = tail.P + off
+        sdf, go = eng.empty(m, 1), eng.empty(m, 3)          # own storage: outputs must not alias the workspace
+        _lib.check(eng.lib.es_copy2(_lib.ptr(sdf), _lib.ptr(pctx.view("sdf")[r0:]), m, _lib.ptr(go), _lib.ptr(pctx.view("go")[r0:]), 3 * m,
+                                    eng.st()), "es_copy2")
+        ctx.tail, ctx.eng, ctx.off, ctx.m = tail, eng, off, m
+        ctx.set_materialize_grads(False)
+        return sdf, go
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_go):
+        tail, eng, off, m = ctx.tail, ctx.eng, ctx.off, ctx.m
+        f = lambda g: None if g is None else g.detach().to(torch.float32).contiguous()
+        d_sdf, d_go = f(d_sdf), f(d_go)
+        if d_sdf is not None or d_go is not None:
+            _lib.check(eng.lib.es_copy2(_lib.ptr(tail.g_sdf[off:]), _lib.ptr(d_sdf), m if d_sdf is not None else 0,
+                                        _lib.ptr(tail.g_go[off:]), _lib.ptr(d_go), 3 * m if d_go is not None else 0, eng.st()), "es_copy2")
+        return None, None, None, None, None
+
+
+class _EodLossFn(torch.autograd.Function):
+    """errorondepth's reductions (reference endosurf.py:302-317) as one launch, backward one launch (es_eod_loss / es_eod_loss_backward)."""
+
+    @staticmethod
+    def forward(ctx, sdf, g_o, eng: Engine, rays, pts, mask):
+        N = rays.shape[0]
+        f = lambda a: a.detach().to(torch.float32).contiguous()
+        sdf_, go_, rays_, pts_, mask_ = f(sdf), f(g_o), f(rays), f(pts), f(mask)
+        if not (sdf_.numel() == N and go_.numel() == 3 * N and pts_.numel() == 3 * N and mask_.numel() == N):
+            raise ValueError("errorondepth expects one point, one sdf, one gradient and one mask value per ray")
+        out, inside = eng.empty(3), eng.empty(N, 1)
+        _lib.check(eng.lib.es_eod_loss(_lib.ptr(rays_), _lib.ptr(pts_), _lib.ptr(mask_), _lib.ptr(sdf_), _lib.ptr(go_), N, _lib.ptr(out),
+                                       _lib.ptr(inside), eng.st()), "es_eod_loss")
+        ctx.eng, ctx.saved, ctx.n = eng, (rays_, inside, sdf_, go_, out), N
+        ctx.shapes = (tuple(sdf.shape), tuple(g_o.shape))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(inside)
+        return out[0], out[1], inside
+
+    @staticmethod
+    def backward(ctx, g_sdf_err, g_ang_err, _g_inside):
+        if g_sdf_err is None and g_ang_err is None:
+            return None, None, None, None, None, None
+        eng, N = ctx.eng, ctx.n
+        rays_, inside, sdf_, go_, out = ctx.saved
+        f = lambda g: None if g is None else g.detach().to(torch.float32).reshape(1)
+        ga, gb = f(g_sdf_err), f(g_ang_err)
+        d_sdf, d_go = eng.empty(N, 1), eng.empty(N, 3)
+        _lib.check(eng.lib.es_eod_loss_backward(_lib.ptr(rays_), _lib.ptr(inside), _lib.ptr(sdf_), _lib.ptr(go_), _lib.ptr(out), _lib.ptr(ga),
+                                                _lib.ptr(gb), N, _lib.ptr(d_sdf), _lib.ptr(d_go), eng.st()), "es_eod_loss_backward")
+        return d_sdf.view(ctx.shapes[0]), d_go.view(ctx.shapes[1]), None, None, None, None
+
+
+class _SnLossFn(torch.autograd.Function):
+    """surface_neighbour_error's reduction (reference endosurf.py:334-339) as one launch, backward one launch."""
+
+    @staticmethod
+    def forward(ctx, g, eng: Engine, valid):
+        N = valid.numel()
+        g_ = g.detach().to(torch.float32).contiguous()
+        if g_.numel() != 6 * N:
+            raise ValueError("surface_neighbour_error expects the gradients of N surface points followed by their N neighbours")
+        v8 = (valid.view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8)).contiguous()
+        out = eng.empty(2)
+        _lib.check(eng.lib.es_sn_loss(_lib.ptr(g_), _lib.ptr(v8), N, _lib.ptr(out), eng.st()), "es_sn_loss")
+        ctx.eng, ctx.saved, ctx.n, ctx.shape = eng, (g_, v8, out), N, tuple(g.shape)
+        ctx.set_materialize_grads(False)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        if g_loss is None:
+            return None, None, None
+        eng, N = ctx.eng, ctx.n
+        g_, v8, out = ctx.saved
+        gl = g_loss.detach().to(torch.float32).reshape(1)
+        d_g = eng.empty(2 * N, 3)
+        _lib.check(eng.lib.es_sn_loss_backward(_lib.ptr(g_), _lib.ptr(v8), _lib.ptr(out), _lib.ptr(gl), N, _lib.ptr(d_g), eng.st()),
+                   "es_sn_loss_backward")
+        return d_g.view(ctx.shape), None, None
+
+
 class _RenderFn(torch.autograd.Function):
     """render_core (reference endosurf.py:134-213) on fixed sample depths: fused point evaluation + compositing.
     Optionally evaluates ``aux_x/aux_t`` (colour-less points: errorondepth / surface-neighbour points of a training step)
@@ -505,9 +619,12 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weff, packed, variance, eng: Engine, rays, z, sample_dist: float, cos_anneal: float, flags: int, aux_x, aux_t,
-                chunk_rays: int):
+                chunk_rays: int, tail=None):
+        """``tail`` (a fresh ``_Tail``; only without ``aux_x`` / chunking): lay the workspace out with ``tail.cap`` extra colour-less rows for
+        the point evaluations of later calls; the last output (``token``) ties their autograd nodes to this one."""
         N, S = z.shape
         P_ = N * S
+        ctx.tail = None
         ctx.set_materialize_grads(False)          # unused outputs (weights, cdf, ...) arrive as None, not as zero-filled tensors
         var1 = variance.detach().reshape(1)
         ctx.eng, ctx.weff, ctx.packed, ctx.variance = eng, weff, packed, variance
@@ -536,12 +653,20 @@ class _RenderFn(torch.autograd.Function):
             den_out = ctx.eik_den.clone()
             ctx.mark_non_differentiable(cat["wmax_idx"], den_out)
             return (cat["color"], cat["depth"], cat["go"], eik, cat["weights"], cat["weight_max"], cat["cdf"], cat["wmax_idx"],
-                    eng.zeros(0, 1), eng.zeros(0, 3), den_out)
+                    eng.zeros(0, 1), eng.zeros(0, 3), den_out, eng.empty(1))
         ctx.chunk_rays = 0
         mid = eng.mid_z(z, sample_dist)
         fused = aux_x is not None and aux_x.shape[0] > 0 and P_ % 64 == 0
-        pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=aux_x if fused else None, t=aux_t if fused else None)
-        pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR, m_color=P_ if fused else 0)
+        if tail is not None and not fused and (flags & _lib.PF_SAVE) and P_ % 64 == 0 and P_ > 0:
+            # the colour part of a workspace laid out for P + cap rows; the tail's rows are evaluated by the calls that claim them
+            pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=tail.aux_x, t=tail.aux_t)
+            pctx = PointCtx(eng, pts, flags | _lib.PF_COLOR, m_color=P_)
+            eng.point_forward_rows(pctx, weff, packed, 0, P_)
+            tail.pctx, tail.weff, tail.flags = pctx, weff, flags
+            ctx.tail = tail
+        else:
+            pts = eng.points(rays=rays, z=mid, n_per_ray=S, ldz=S, x=aux_x if fused else None, t=aux_t if fused else None)
+            pctx = eng.point_forward(pts, weff, packed, flags | _lib.PF_COLOR, m_color=P_ if fused else 0)
         sdf_all, go_all = pctx.view("sdf"), pctx.view("go")
         a = eng.composite_args(rays, z, sdf_all.view(-1), go_all, pctx.view("rgb"), var1, sample_dist, cos_anneal)
         # own storage for every output (the 6.7 GB workspace must not outlive the backward): the compositing launch writes the samples'
@@ -559,11 +684,24 @@ class _RenderFn(torch.autograd.Function):
         ctx.n_aux = n_aux
         ctx.mark_non_differentiable(out["wmax_idx"], den_out)
         return (out["color"], out["depth"], out["go"], eik.reshape(()), out["weights"], out["weight_max"], out["cdf"], out["wmax_idx"], aux_sdf,
-                aux_go, den_out)
+                aux_go, den_out, eng.empty(1))
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go, _g_den=None):
+    def backward(ctx, g_color, g_depth, g_go, g_eik, g_weights, g_wmax, g_cdf, _, g_aux_sdf, g_aux_go, _g_den=None, _g_token=None):
         eng = ctx.eng
+        tail = ctx.tail
+        if tail is not None:
+            # the later calls' points behind the samples: their nodes have run (they depend on this one through the token) and left
+            # their adjoints in the tail's buffers; rows nobody claimed are evaluated now, with zero adjoints
+            if tail.pctx is not None and tail.used < tail.cap:
+                eng.point_forward_rows(tail.pctx, ctx.weff, ctx.packed, tail.P + tail.used, tail.cap - tail.used)
+                tail.used = tail.cap
+            ctx.n_aux, g_aux_sdf, g_aux_go = tail.cap, tail.g_sdf, tail.g_go
+            if ctx.pctx is None:          # a second backward through this node: re-evaluate everything (main rows + the whole tail)
+                rays_, zs_, sd_, _ = ctx.geom
+                mid = eng.mid_z(zs_, sd_)
+                pts = eng.points(rays=rays_, z=mid, n_per_ray=zs_.shape[1], ldz=zs_.shape[1], x=tail.aux_x, t=tail.aux_t)
+                ctx.pctx = eng.point_forward(pts, ctx.weff, ctx.packed, ctx.flags | _lib.PF_COLOR, m_color=zs_.numel(), fp32_only=True)
         if not (ctx.flags & _lib.PF_SAVE):
             raise RuntimeError("render was run without saved activations; cannot backpropagate")
         rays, zs, sample_dist, cos_anneal = ctx.geom
@@ -598,7 +736,9 @@ class _RenderFn(torch.autograd.Function):
         # inv_s = clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :852): d var = d inv_s * 10 exp(10 var) inside the clip range
         dvar = eng.variance_terms(var, d_invs_acc=d_invs_acc).reshape(ctx.variance.shape)
         ctx.pctx = None                                           # release the workspace as soon as it has been consumed
-        return dweff, None, dvar, None, None, None, None, None, None, None, None, None
+        if tail is not None:
+            tail.pctx = None
+        return dweff, None, dvar, None, None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -904,9 +1044,13 @@ class EndoSurfRenderer(nn.Module):
             aux_x = _aux[0].detach().to(torch.float32).contiguous()
             aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
         flags = self._flags(weff)
-        color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go, eik_den = _RenderFn.apply(
+        chunk = self._chunk_rays(z.shape[0], z.shape[1], flags)
+        tail = self._new_tail(z.numel(), flags, chunk) if _aux is None else None
+        color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go, eik_den, token = _RenderFn.apply(
             weff, packed, var, self.engine, _rays, z, float(sample_dist), cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), flags, aux_x, aux_t,
-            self._chunk_rays(z.shape[0], z.shape[1], flags))
+            chunk, tail)
+        # (the renderer holds the token, the token's node holds the tail: no reference from the tail back to either)
+        self._live_tail = (tail, token) if (tail is not None and tail.pctx is not None) else None
         if _aux is not None and aux_sdf.shape[0] != aux_x.shape[0]:      # tile-unaligned sample count: separate launch
             aux_sdf, aux_go = self._point_eval(aux_x, aux_t)
         s_val = _SValFn.apply(var, self.engine)                 # 1 / clip(exp(10 var), 1e-6, 1e6)  (endosurf.py:168, :205)
@@ -920,9 +1064,19 @@ class EndoSurfRenderer(nn.Module):
         (d <g_o, w> / d x, the reference's create_graph=True second derivative); the returned sdf does NOT (callers attach d sdf / d x
         = g_o themselves)."""
         weff, packed = self._weights()
+        flags = self._flags(weff)
+        if (flags & _lib.PF_SAVE) and not canonical and x_in is None and dirs is None:
+            # a grad-enabled colour-less evaluation: into the tail of the live render if there is room (see _Tail), and counted either way
+            xx, tt = x.detach().to(torch.float32).reshape(-1, 3), t.detach().to(torch.float32).reshape(-1)
+            slot = self._tail_slot(xx.shape[0], weff, flags)
+            if slot is not None and tt.numel() == xx.shape[0]:
+                eng, m = self.engine, xx.shape[0]
+                if xx.data_ptr() != slot[2].data_ptr():          # (errorondepth / surface_neighbour_error write their points in place)
+                    _lib.check(eng.lib.es_copy2(_lib.ptr(slot[2]), _lib.ptr(xx.contiguous()), 3 * m, _lib.ptr(slot[3]), _lib.ptr(tt.contiguous()), m,
+                                                eng.st()), "es_copy2")
+                return self._tail_eval(slot, m, weff, packed)
         pts = self.engine.points(x=x.detach().to(torch.float32).contiguous(), t=t.detach().to(torch.float32).reshape(-1).contiguous(),
                                  dirs=dirs)
-        flags = self._flags(weff)
         if canonical:
             flags &= ~_lib.PF_DEFORM
         if x_in is not None:
@@ -931,30 +1085,71 @@ class EndoSurfRenderer(nn.Module):
             sdf, g_o = _PointEvalFn.apply(weff, packed, self.engine, pts, flags)
         return sdf, g_o
 
+    # ---- the tail of a live render (see _Tail) -------------------------------------------------------------------------------------------
+    def _new_tail(self, P_: int, flags: int, chunk: int):
+        """A ``_Tail`` for the render about to run, sized by what the calls after the PREVIOUS grad-enabled render asked for (the reference
+        trainer's step repeats the same three calls); None when nothing was asked for or the render cannot host one."""
+        if not (flags & _lib.PF_SAVE):
+            return None
+        demand, self._aux_demand = getattr(self, "_aux_demand", 0), 0
+        eng = self.engine
+        if demand <= 0 or chunk or P_ <= 0 or P_ % 64 or eng.split_precision or torch.cuda.is_current_stream_capturing():
+            return None
+        cap = demand + (-(P_ + demand)) % 128          # workspace rows come in blocks of 128: no row of the last block is left undefined
+        return _Tail(eng, P_, cap)
+
+    def _tail_slot(self, m: int, weff, flags: int, count: bool = True):
+        """(tail, row offset, x view [m,3], t view [m]) in the live render's tail for ``m`` more colour-less points, or None.
+        ``count``: add the request to the demand the next render sizes its tail by."""
+        m64 = (m + 63) // 64 * 64
+        if count:
+            self._aux_demand = getattr(self, "_aux_demand", 0) + m64
+        live = getattr(self, "_live_tail", None)
+        if live is None or m == 0 or not torch.is_grad_enabled():
+            return None
+        tail = live[0]
+        if not tail.room(m64, weff, flags):
+            return None
+        off = tail.used
+        return tail, off, tail.aux_x[off:off + m], tail.aux_t[off:off + m]
+
+    def _tail_eval(self, slot, m: int, weff, packed):
+        tail, off = slot[0], slot[1]
+        m64 = (m + 63) // 64 * 64
+        tail.used = off + m64
+        self.engine.point_forward_rows(tail.pctx, weff, packed, tail.P + off, m64)
+        return _TailEvalFn.apply(self._live_tail[1], tail, self.engine, off, m)
+
+    def _aux_buffers(self, m: int):
+        """Where a call's ``m`` colour-less points are written: straight into the live render's tail when it has room, else fresh buffers."""
+        weff, _ = self._weights()
+        flags = self._flags(weff)
+        slot = self._tail_slot(m, weff, flags, count=False) if (flags & _lib.PF_SAVE) else None      # (_point_eval does the counting)
+        if slot is not None:
+            return slot[2], slot[3]
+        return self.engine.empty(m, 3), self.engine.empty(m)
+
     @_on_device
     def errorondepth(self, rays, d_gt, mask, iter_step=0):
+        """reference errorondepth (endosurf.py:289-317): three library launches (points, evaluation, reductions) + the evaluation's own."""
         rays = self._rays32(rays)
         pts, time = self._eod_points(rays, d_gt)
         sdf, gradient_o = self._point_eval(pts, time)
         return self._eod_loss(rays, pts, mask, sdf, gradient_o)
 
-    @staticmethod
-    def _eod_points(rays, d_gt):
-        rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
-        rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
-        return (rays_o + rays_d_z * d_gt).reshape(-1, 3), time
+    def _eod_points(self, rays, d_gt):
+        """o + d / (d.z + 1e-6) * d_gt and the rays' times (endosurf.py:297-300), one launch (es_eod_points)."""
+        N = rays.shape[0]
+        x, t = self._aux_buffers(N)
+        d = d_gt.detach().to(torch.float32).reshape(-1).contiguous()
+        if d.numel() != N:
+            raise ValueError("errorondepth expects one ground-truth depth per ray")
+        _lib.check(self.engine.lib.es_eod_points(_lib.ptr(rays), _lib.ptr(d), N, _lib.ptr(x), _lib.ptr(t), self.engine.st()), "es_eod_points")
+        return x, t
 
     def _eod_loss(self, rays, pts, mask, sdf, gradient_o):
-        rays_d = rays[:, 3:6]
-        true_cos = (rays_d * gradient_o).sum(-1, keepdim=True)
-        relu_cos = torch.relu(true_cos)
-        pts_norm = torch.linalg.norm(pts.detach(), ord=2, dim=-1, keepdim=True)
-        inside_masksphere = (pts_norm < 1.0).to(self.dtype) * mask
-        sdf = inside_masksphere * sdf
-        denom = inside_masksphere.sum() + 1e-6
-        sdf_error = sdf.abs().sum() / denom
-        angle_error = relu_cos.abs().sum() / denom          # not masked, like the reference (endosurf.py:315)
-        return sdf_error, angle_error, inside_masksphere
+        """(sdf_error, angle_error, inside_masksphere [N,1]) (endosurf.py:302-317; the angle term is not masked, like the reference)."""
+        return _EodLossFn.apply(sdf, gradient_o, self.engine, rays, pts, mask)
 
     @_on_device
     def ray_marching(self, rays, tau=0.0, n_steps=(128, 129), n_secant_steps=8, max_points=64000):
@@ -983,18 +1178,28 @@ class EndoSurfRenderer(nn.Module):
             return self.engine.march_refine(ms)
 
     def _sn_points(self, rays, mask, neighbour_rad, u_neigh=None, d_i=None):
+        """(x [2N,3], t [2N], valid [N] bool): the surface points (ray marching + secant, no grad) and their random neighbours
+        (endosurf.py:321-332) in one launch (es_sn_points) behind the marching's."""
         N = rays.shape[0]
-        rays_o, rays_d, time = rays[:, :3], rays[:, 3:6], rays[:, 8]
-        rays_d_z = rays_d / (rays_d[:, 2:] + 1e-6)
+        eng = self.engine
+        f = lambda a: a.detach().to(torch.float32).contiguous()
+        x, t = self._aux_buffers(2 * N)
         with torch.no_grad():
             if d_i is None:
                 d_i = self.ray_marching(rays)
-            valid = (torch.isfinite(d_i) & (d_i != 0) & (mask == 1))[:, 0]
-            d_safe = torch.where(valid[:, None], d_i, torch.zeros_like(d_i))
-            p_surf = rays_o + d_safe * rays_d_z
-            u = u_neigh if u_neigh is not None else torch.rand(N, 3, device=self.device)
-            p_neig = p_surf + (u.to(torch.float32) - 0.5) * neighbour_rad
-            return torch.cat([p_surf, p_neig], 0).contiguous(), torch.cat([time, time], 0).contiguous(), valid
+            if u_neigh is not None:
+                u = f(u_neigh)
+            elif torch.cuda.is_current_stream_capturing():      # (a captured graph needs torch's graph-safe generator)
+                u = torch.rand(N, 3, device=self.device)
+            else:
+                u = eng.uniform(3 * N).view(N, 3)
+            m = f(mask).reshape(-1)
+            if m.numel() != N:
+                raise ValueError("surface_neighbour_error expects one mask value per ray")
+            valid = eng.empty(N, dtype=torch.bool)
+            _lib.check(eng.lib.es_sn_points(_lib.ptr(rays), _lib.ptr(m), _lib.ptr(f(d_i).reshape(-1)), _lib.ptr(u), float(neighbour_rad), N, _lib.ptr(x),
+                                            _lib.ptr(t), _lib.ptr(valid), eng.st()), "es_sn_points")
+            return x, t, valid
 
     def _train_aux_points(self, rays, depth_gt, mask, d_i, neighbour_rad, u_neigh=None):
         """(x [3N,3], t [3N], valid [N] bool): the points of _eod_points and _sn_points (same arithmetic) in one launch."""
@@ -1009,10 +1214,8 @@ class EndoSurfRenderer(nn.Module):
         return x, t, valid
 
     def _sn_loss(self, g, valid):
-        N = valid.shape[0]
-        normal = g / (torch.linalg.norm(g, ord=2, dim=-1, keepdim=True) + 1e-10)
-        diff = (normal[:N] - normal[N:]).abs() * valid[:, None].to(self.dtype)
-        return diff.sum() / torch.clamp(valid.sum() * 3, min=1).to(self.dtype)
+        """mean over the valid rays of |n - n'| (endosurf.py:334-339), 0 when no ray is valid; one launch (es_sn_loss)."""
+        return _SnLossFn.apply(g, self.engine, valid)
 
     # ---- full-frame rendering (the reference's eval loop, trainer_endosurf.py:221-240) -----------------------------------
     @_on_device

@@ -1,0 +1,163 @@
+"""The reference trainer's OWN call sequence through the drop-in (trainer_endosurf.py:130, :140, :155: ``renderer(rays)`` ->
+``errorondepth`` -> ``surface_neighbour_error`` as three calls, one ``loss.backward()``): from the second step on the two later calls'
+points are evaluated into the tail of the live render's workspace and back-propagated by the render's ONE backward chain
+(renderer._Tail).  Same values, same gradients as the stand-alone evaluations -- whatever subset of the three results the loss uses,
+when the tail overflows, and when nobody claims it."""
+import pytest
+import torch
+
+from gpu_util import renderer_for_case
+from oracle_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(c, dev="cuda"):
+    b = dict(rays=torch.from_numpy(c["rays"]).to(dev), color=torch.from_numpy(c["target/color"]).to(dev),
+             depth=torch.from_numpy(c["target/depth"]).to(dev), mask=torch.from_numpy(c["target/mask"]).to(dev),
+             color_mask=torch.from_numpy(c["target/color_mask"]).to(dev))
+    u = torch.from_numpy(c["u_perturb"]).to(dev) if "u_perturb" in c else None
+    return b, u, torch.from_numpy(c["u_neigh"]).to(dev)
+
+
+def _grads(r):
+    return {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in r.named_parameters()}
+
+
+def _step(r, b, u, un, it, use, demand):
+    """One pass of the reference call sequence; ``use``: which of the three calls' results enter the loss; ``demand``: tail rows the
+    render reserves (0: every evaluation stand-alone)."""
+    for p in r.parameters():
+        p.grad = None
+    r._aux_demand = demand
+    r.perturb = u is not None
+    ret = r(b["rays"], iter_step=it, u_perturb=u)
+    tail = r._live_tail[0] if r._live_tail is not None else None
+    sdf_loss, angle_loss, valid = r.errorondepth(b["rays"], d_gt=b["depth"], mask=b["mask"], iter_step=it)
+    sn = r.surface_neighbour_error(rays=b["rays"], mask=b["mask"], iter_step=it, neighbour_rad=0.1, u_neigh=un)
+    loss = 0.0
+    if "render" in use:
+        loss = loss + ((ret["color_map"] - b["color"]) * b["color_mask"]).abs().sum() / (b["color_mask"].sum() + 1e-10) + 0.1 * ret["gradient_o_error"]
+        loss = loss + ((ret["depth_map"] - b["depth"]) * valid * b["mask"]).abs().sum() / ((valid * b["mask"]).sum() + 1e-10)
+    if "eod" in use:
+        loss = loss + sdf_loss + 0.1 * angle_loss
+    if "sn" in use:
+        loss = loss + 0.1 * sn
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss), (float(sdf_loss), float(angle_loss), float(sn)), _grads(r), tail
+
+
+def _close(ga, gb, tol=3e-4):
+    for k in ga:
+        n = float(ga[k].norm())
+        assert float((ga[k] - gb[k]).norm()) <= tol * n + 1e-7, (k, float((ga[k] - gb[k]).norm()), n)
+
+
+@pytest.mark.parametrize("name", ["trained_deform", "trained_nodeform"])
+@pytest.mark.parametrize("use", [("render", "eod", "sn"), ("eod", "sn"), ("sn",), ("render",)])
+def test_tail_equals_standalone(name, use):
+    c = load_case(name)
+    b, u, un = _batch(c)
+    it = int(c["meta/iter_step"])
+    r = renderer_for_case(c)
+    r.engine.deterministic = True
+    N = b["rays"].shape[0]
+    l0, t0, g0, tail0 = _step(r, b, u, un, it, use, demand=0)
+    assert tail0 is None
+    need = (N + 63) // 64 * 64 + (2 * N + 63) // 64 * 64
+    assert r._aux_demand == need                         # what the next render will reserve
+    l1, t1, g1, tail1 = _step(r, b, u, un, it, use, demand=need)
+    assert tail1 is not None and tail1.cap >= need and tail1.used == tail1.cap and tail1.pctx is None
+    assert t0 == t1                                      # the forward values: same kernels' arithmetic, bit for bit
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    _close(g0, g1)
+    # steady state: the demand the second step measured is the same again
+    assert r._aux_demand == need
+
+
+def test_tail_overflow_and_unclaimed_rows():
+    c = load_case("trained_deform")
+    b, u, un = _batch(c)
+    it = int(c["meta/iter_step"])
+    r = renderer_for_case(c)
+    r.engine.deterministic = True
+    use = ("render", "eod", "sn")
+    _, t0, g0, _ = _step(r, b, u, un, it, use, demand=0)
+    # room for errorondepth's points only: surface_neighbour_error overflows into a stand-alone evaluation
+    _, t1, g1, tail = _step(r, b, u, un, it, use, demand=64)
+    assert tail is not None and t0 == t1
+    _close(g0, g1)
+    # far more room than anybody claims: the unclaimed rows are evaluated (zero adjoints) before the backward
+    _, t2, g2, tail = _step(r, b, u, un, it, use, demand=1024)
+    assert tail is not None and tail.cap >= 1024 and t0 == t2
+    _close(g0, g2)
+    for k, g in g2.items():
+        assert bool(torch.isfinite(g).all()), k
+
+
+def test_tail_second_render_before_backward():
+    """Two grad-enabled renders before one backward: the later calls go to the LATEST render's tail; both renders back-propagate."""
+    c = load_case("trained_deform")
+    b, u, un = _batch(c)
+    it = int(c["meta/iter_step"])
+    res = []
+    for demand in (0, 256):
+        r = renderer_for_case(c)
+        r.engine.deterministic = True
+        r.perturb = u is not None
+        r._aux_demand = demand
+        ret_a = r(b["rays"], iter_step=it, u_perturb=u)
+        r._aux_demand = demand
+        ret_b = r(b["rays"], iter_step=it, u_perturb=u)
+        sdf_loss, angle_loss, _ = r.errorondepth(b["rays"], d_gt=b["depth"], mask=b["mask"], iter_step=it)
+        loss = ret_a["color_map"].sum() + ret_b["depth_map"].sum() + sdf_loss + angle_loss
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), _grads(r)))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * max(1.0, abs(res[0][0]))
+    _close(res[0][1], res[1][1])
+
+
+def test_aux_loss_kernels_match_torch():
+    """es_eod_loss / es_sn_loss and their backward against the reference's op chains in torch (endosurf.py:302-317, :334-339)."""
+    from endosurf_amd.renderer import _EodLossFn, _SnLossFn
+    c = load_case("trained_deform")
+    r = renderer_for_case(c)
+    eng = r.engine
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N = 777
+    rays = torch.randn(N, 9, generator=g, device="cuda")
+    pts = torch.randn(N, 3, generator=g, device="cuda") * 0.7
+    mask = (torch.rand(N, 1, generator=g, device="cuda") > 0.3).float()
+    sdf = torch.randn(N, 1, generator=g, device="cuda", requires_grad=True)
+    go = torch.randn(N, 3, generator=g, device="cuda", requires_grad=True)
+    a, bb, inside = _EodLossFn.apply(sdf, go, eng, rays, pts, mask)
+    (2.0 * a + 3.0 * bb).backward()
+    got = (float(a), float(bb), sdf.grad.clone(), go.grad.clone(), inside.clone())
+    sdf.grad = go.grad = None
+    ins = (pts.norm(dim=-1, keepdim=True) < 1.0).float() * mask
+    den = ins.sum() + 1e-6
+    ra, rb = (ins * sdf).abs().sum() / den, torch.relu((rays[:, 3:6] * go).sum(-1, keepdim=True)).abs().sum() / den
+    (2.0 * ra + 3.0 * rb).backward()
+    assert abs(got[0] - float(ra)) < 1e-5 * abs(float(ra)) and abs(got[1] - float(rb)) < 1e-5 * abs(float(rb))
+    assert torch.equal(got[4], ins)
+    assert float((got[2] - sdf.grad).abs().max()) < 1e-6 * float(sdf.grad.abs().max())
+    assert float((got[3] - go.grad).abs().max()) < 1e-6 * float(go.grad.abs().max())
+    # surface-neighbour term, incl. a zero gradient row (torch's norm backward gives 0 there) and the no-valid-ray case
+    gg = torch.randn(2 * N, 3, generator=g, device="cuda")
+    gg[5] = 0.0
+    gg.requires_grad_(True)
+    valid = torch.rand(N, generator=g, device="cuda") > 0.4
+    valid[5] = True
+    out = _SnLossFn.apply(gg, eng, valid)
+    (1.7 * out).backward()
+    got = (float(out), gg.grad.clone())
+    gg.grad = None
+    nrm = gg / (gg.norm(dim=-1, keepdim=True) + 1e-10)
+    ref = ((nrm[:N] - nrm[N:]).abs() * valid[:, None].float()).sum() / torch.clamp(valid.sum() * 3, min=1).float()
+    (1.7 * ref).backward()
+    assert abs(got[0] - float(ref)) < 1e-5 * abs(float(ref))
+    assert float((got[1] - gg.grad).abs().max()) < 2e-6 * float(gg.grad.abs().max())
+    none = _SnLossFn.apply(gg.detach(), eng, torch.zeros(N, dtype=torch.bool, device="cuda"))
+    assert float(none) == 0.0
