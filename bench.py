@@ -618,9 +618,13 @@ class ReferenceLoop:
         return v
 
     def measure(self, warmup, steps, timing_steps=3):
+        """``ms_per_step``: the data-independent step (all 128 marching proposals of every ray, like the headline's ``value``); the package
+        default (early exit at each ray's first sign change, bit-identical results) is timed next to it as ``with_early_exit``."""
         import torch
         from endosurf_amd import _lib
         eng = self.renderer.engine
+        march_block = eng.march_block
+        eng.march_block = 0
         for i in range(warmup):
             self.train_step(i)
         torch.cuda.synchronize()
@@ -635,12 +639,30 @@ class ReferenceLoop:
         # (a logging step blocks on its host reads in the middle: "time to enqueue" is only defined for the plain step)
         issue = None if self.logging else sorted(self.t_issue)[len(self.t_issue) // 2] * 1e3
         syncs = 1 + (self.scalars // steps + 3 if self.logging else 0)
-        timing = kernel_timing(eng, self.train_step, warmup + steps, timing_steps, self.cfg["use_deform"])
+        nxt = warmup + steps
+        timing = kernel_timing(eng, self.train_step, nxt, timing_steps, self.cfg["use_deform"])
+        nxt += timing_steps
         per = timing.get("per_step_ms") or {}
+        early = None
+        if march_block:
+            eng.march_block = march_block
+            self.train_step(nxt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.train_step(nxt + 1 + i)
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t0
+            early = dict(ms_per_step=dte / steps * 1e3, value=self.cfg["rays"] * steps / dte, block=march_block,
+                         note="the package default; bit-identical results, data-dependent saving (how many rays have passed their first sign "
+                              "change after each block of proposals)")
         opt = self.optimizer
+        tail = (self.renderer.__dict__.get("_live_tail") or (None,))[0]
         return dict(ms_per_step=dt / steps * 1e3, value=self.cfg["rays"] * steps / dt, unit="rays/s", steps=steps, warmup=warmup,
+                    ray_marching="all 128 proposals of every ray (data independent, as the reference)", with_early_exit=early,
                     host_issue_ms=issue, host_syncs_per_step=syncs, library_calls_per_step=calls,
                     sum_timed_kernel_ms=sum(per.values()) if per else None, kernel_ms_per_step=per or None,
+                    aux_rows_in_render_workspace=(tail.cap if tail is not None else 0),
                     optimizer="torch.optim.Adam(params=grad_vars, lr) over %d tensors, torch defaults (%s)" % (
                         len(opt.param_groups[0]["params"]),
                         "foreach" if opt.param_groups[0].get("foreach") in (None, True) and not opt.param_groups[0].get("fused") else "fused"))

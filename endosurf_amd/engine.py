@@ -251,6 +251,15 @@ class Engine:
         sample_dist = 2.0 / n_samples
         do_up = upsample and n_importance > 0 and up_sample_steps > 0
         S = n + (n_importance if do_up else 0)
+        if do_up and not racing and trace is None and N > 0 and n_importance % up_sample_steps == 0 and not self._use_x3(N * n):
+            # the same launches in the same order, issued by ONE library call (es_sample_z) instead of ~15: a step that ends in a host
+            # sync (the reference trainer's loss.item()) starts with an empty queue, and this chain of small launches is where the GPU
+            # would wait for the host
+            z_out = self.empty(N, S)
+            scratch = self.empty(int(self.lib.es_sample_scratch_floats(N, n_samples, n_importance, up_sample_steps)))
+            check(self.lib.es_sample_z(ptr(rays), ptr(u_perturb) if u_perturb is not None else None, N, n_samples, n_importance, up_sample_steps, 1,
+                                       ptr(packed), ptr(weff), int(use_deform), ptr(z_out), ptr(scratch), self.st()), "es_sample_z")
+            return z_out
         zc = self.empty(N, S)
         self.ray_setup(rays, u_perturb, n, sample_dist, 0, zc)
         if trace is not None:
@@ -402,6 +411,16 @@ class Engine:
 
     def ray_marching(self, rays, weff, packed, use_deform, n_steps=128, n_secant_steps=8, tau=0.0):
         """ray_marching + secant (reference endosurf.py:344-449), fixed shape. Returns d_pred [N,1]."""
+        N = rays.shape[0]
+        B = self.march_block
+        blocks = bool(B and n_steps % B == 0 and n_steps > B and N * B >= 16384)
+        if N > 0 and not self._use_x3(N * (B if blocks else n_steps)):
+            # ONE library call (es_ray_marching) issues the proposals' queries, the bracket search and the secant iterations (~30 launches)
+            d_out = self.empty(N, 1)
+            scratch = self.empty(int(self.lib.es_march_scratch_floats(N, n_steps)))
+            check(self.lib.es_ray_marching(ptr(rays), N, int(n_steps), int(n_secant_steps), float(tau), int(B) if blocks else 0, ptr(packed), ptr(weff),
+                                           int(use_deform), ptr(d_out), ptr(scratch), self.st()), "es_ray_marching")
+            return d_out
         return self.march_refine(self.march_begin(rays, weff, packed, use_deform, n_steps, tau), n_secant_steps)
 
 
