@@ -240,7 +240,12 @@ class EndoSurfNet(nn.Module):
         return ckpt
 
     def ordered_params(self):
-        """(key, Parameter) in flat-buffer order, variance excluded."""
+        """(key, Parameter) in flat-buffer order, variance excluded.  (Built once: the modules and the identity of their Parameters are
+        fixed for the life of the model -- ``_rebind`` / ``_apply`` only re-point ``.data`` -- and the renderer's ``_weights()`` walks this
+        list several times per call of every public method.)"""
+        cached = self.__dict__.get("_ordered")
+        if cached is not None:
+            return list(cached)
         out = []
         for net in P.NET_NAMES:
             if net == "deform_network" and not self.use_deform:
@@ -249,6 +254,11 @@ class EndoSurfNet(nn.Module):
             for l in range(9):
                 for name in ("bias", "weight_g", "weight_v"):
                     out.append((f"{net}.net.{l}.{name}", getattr(mod.net[l], name)))
+        self.__dict__["_ordered"] = tuple(out)
+        self.__dict__["_plist"] = tuple(p for _, p in out)
+        var = self.deviation_network.variance
+        base = self._layout
+        self.__dict__["_view_slots"] = tuple((p, 4 * base[k][0]) for k, p in out) + ((var, 4 * base["deviation_network.variance"][0]),)
         return out
 
     # ---- flat-buffer binding -------------------------------------------------------------------------------------------
@@ -275,13 +285,22 @@ class EndoSurfNet(nn.Module):
         self._rebind()
         return self
 
-    def _check_views(self):
+    def _check_views(self, spot: bool = False):
         """Every parameter must still be a view of the flat buffer; anything that re-bound parameter storage (``p.data = ...``
-        loaders, DDP/FSDP flattening, ...) is folded back into it."""
+        loaders, DDP/FSDP flattening, ...) is folded back into it.  ``spot``: look at the first and the last tensor only (the renderer
+        does the full walk once per parameter version and this one at every other call)."""
         base = self._flat.data_ptr()
-        pairs = self.ordered_params() + [("deviation_network.variance", self.deviation_network.variance)]
-        if all(p.data_ptr() == base + 4 * self._layout[k][0] for k, p in pairs):
+        slots = self.__dict__.get("_view_slots")
+        if slots is None:
+            self.ordered_params()
+            slots = self.__dict__["_view_slots"]
+        if spot:
+            (p0, o0), (p1, o1) = slots[0], slots[-1]
+            if p0.data_ptr() == base + o0 and p1.data_ptr() == base + o1:
+                return
+        if all(p.data_ptr() == base + o for p, o in slots):
             return
+        pairs = self.ordered_params() + [("deviation_network.variance", self.deviation_network.variance)]
         with torch.no_grad():
             for k, p in pairs:
                 off, shape = self._layout[k]
@@ -800,13 +819,21 @@ class EndoSurfRenderer(nn.Module):
     # ---- weights: weight-norm + MFMA packing once per parameter version ------------------------------------------
     def _weights(self):
         m = self.model
-        m._check_views()
-        plist = [p for _, p in m.ordered_params()]
+        plist = m.__dict__.get("_plist")
+        if plist is None:
+            m.ordered_params()
+            plist = m.__dict__["_plist"]
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
         key = ((tuple(p._version for p in plist), m._epoch), want_grad)
         c = m._pack_cache
         if c is not None and c[0] == key:
-            return c[1], c[2]
+            m._check_views(spot=True)
+            if m._pack_cache is c:          # (a re-bound parameter was folded back: _rebind dropped the cache)
+                return c[1], c[2]
+        m._check_views()
+        key = ((tuple(p._version for p in plist), m._epoch), want_grad)          # (after the walk: folding a parameter back bumps the epoch)
+        c = m._pack_cache
+        plist = list(plist)
         if c is not None and not want_grad and c[0] == (key[0], True):
             return c[1].detach(), c[2]          # same weights already packed by a grad-enabled call: no need to repack
         if want_grad:
