@@ -23,7 +23,7 @@ namespace es {
 // kernels (1024 + 48 tiles), which costs a full tile time.  Every main launch of this workload is a whole number of rounds,
 // so extra tiles always cost something -- least inside a launch of MANY short rounds: the tail's two dependent stages
 // (deform, then SDF) are therefore mixed into the two halves of the 8-round deformation launch of the main tiles.
-enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP, FB_SDF_VJP, FB_DEFORM_HALF };
+enum FwdBody { FB_NONE = 0, FB_DEFORM, FB_SDF, FB_COLOR, FB_VJP, FB_SDF_VJP, FB_DEFORM_HALF, FB_SDF_VJP_HALF, FB_SDF_HALF };
 template <int B>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
     if constexpr (B == FB_DEFORM) deform_fwd_tile(a, tile);
@@ -35,7 +35,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, int tile) {
         sdf_fwd_tile(a, tile);
         __syncthreads();
         deform_vjp_tile(a, tile);
-    }
+    } else if constexpr (B == FB_SDF_VJP_HALF) {      // the same on 32-row half tiles (stand-alone pieces of a tail: es_point_forward_rows)
+        sdf_fwd_tile<true>(a, tile);
+        __syncthreads();
+        deform_vjp_tile<true>(a, tile);
+    } else if constexpr (B == FB_SDF_HALF) sdf_fwd_tile<true>(a, tile);
 }
 template <int B0, int B1>
 __global__ __launch_bounds__(NTHREADS, 2) void k_point_fwd(FwdArgs a, int n0, int t0, int t1) {
@@ -145,7 +149,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
 // workspace -- with the tail's stages mixed into the main launches (point_bwd.hip) -- replaces three separate backward chains, two of them
 // latency-bound (16 - 32 workgroups) launches at a tile's full latency each.
 //   row0 == 0, nrows == m_color:  the main part (colour points): deform | sdf | colour | vjp over its tiles only
-//   row0 >= m_color:              a piece of the colour-less tail (row0, nrows multiples of 64): deform on half-height tiles | [sdf + vjp]
+//   row0 >= m_color:              a piece of the colour-less tail (row0, nrows multiples of 64): deform | [sdf + vjp], both on half-height tiles
 // fp32 family only.
 int point_forward_rows(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, int row0, int nrows,
                        hipStream_t st) {
@@ -168,10 +172,10 @@ int point_forward_rows(const PointSrc& src, const float* packed, const float* we
         return fail(ST_BAD_ARG, "point_forward_rows", "rows: either the whole colour part [0, m_color) or a 64-aligned piece of the colour-less tail");
     if (deform) {
         { ScopedTimer tm(KID_DEFORM_FWD, nrows, st); if (int e = launch_fwd<FB_NONE, FB_DEFORM_HALF>(a, 0, 0, nrows / 16, row0 / 16, st)) return e; }
-        { ScopedTimer tm(KID_SDF_FWD, nrows, st); if (int e = launch_fwd<FB_SDF_VJP, FB_DEFORM>(a, nrows / TM, row0 / TM, 0, 0, st)) return e; }
+        { ScopedTimer tm(KID_SDF_FWD, nrows, st); if (int e = launch_fwd<FB_NONE, FB_SDF_VJP_HALF>(a, 0, 0, nrows / 32, row0 / 32, st)) return e; }
     } else {
         ScopedTimer tm(KID_SDF_FWD, nrows, st);
-        if (int e = launch_fwd<FB_NONE, FB_SDF>(a, 0, 0, nrows / TM, row0 / TM, st)) return e;
+        if (int e = launch_fwd<FB_NONE, FB_SDF_HALF>(a, 0, 0, nrows / 32, row0 / 32, st)) return e;
     }
     return hip_last("point_forward_rows");
 }

@@ -166,7 +166,14 @@ __device__ __forceinline__ void deform_fwd_tile(const FwdArgs& a, const int tile
 // (get_sdf_grad_from_observed_space, endosurf.py:581-601, is exactly this product).  Tile = 64 points, one row per point;
 // masks M_l from the value rows of u_{l+1}.  With PF_SAVE the adjoints r_0..r_7 are kept: paired with the tangent sweep of
 // the backward pass they give this path's weight gradient.
-__device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile) {
+// HALF: ``tile_in`` counts 32-row half tiles; the workgroup runs row tile rt = tile_in & 1 of the 64-row tile tile_in >> 1 (same LDS and
+// workspace layout, half the MFMAs): a stand-alone piece of a colour-less tail is 16 - 32 workgroups at ONE tile's latency, so half the
+// height is ~half the time.
+template <bool HALF = false>
+__device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile_in) {
+    constexpr int RTC = HALF ? 1 : 2;
+    const int tile = HALF ? (tile_in >> 1) : tile_in;
+    const int RT0 = HALF ? (tile_in & 1) : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;          // adjoint of the 52 encoding inputs (skip part + layer 0), rows 52..55 zero
@@ -183,7 +190,7 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     const int hi = lane >> 5;
     float* R = wsb(a, WS_D_R);
 
-    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    const QuadOff<RTC> qo = quad_offsets<RTC>(RT0, 2 * wave, lane);
     if (tid < 64) {
         const float* gc = wsb(a, WS_GC) + (grow0 + tid) * 3;
         g8[tid] = gc[0]; g8[64 + tid] = gc[1]; g8[128 + tid] = gc[2];
@@ -193,7 +200,7 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
     {   // r_7 = mask_7 * (W8^T g_c)
         const float* W8 = a.weff + a.tb.woff[NET_D * LAYERS + 8];
         const MaskWords mk = load_mask_words(MK + (size_t)7 * nt32 * 256, tile, wave, lane);
-        for_quads_noacc<2, 2>(0, 2 * wave, lane, [&](int row, int col) {
+        for_quads_noacc<RTC, 2>(RT0, 2 * wave, lane, [&](int row, int col) {
             const float w0 = W8[col], w1 = W8[256 + col], w2 = W8[512 + col];
             const int qi = ((row >> 5) * 2 + ((col >> 5) & 1)) * 4 + ((row & 31) >> 3);
             float v[4];
@@ -207,16 +214,16 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         const MaskWords mk = load_mask_words(MK + (size_t)(l - 1) * nt32 * 256, tile, wave, lane);     // in flight during the GEMM
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
-        if (l == 3) gemm_seg<26, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], 0, 2 * wave, lane);
-        else gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], 0, 2 * wave, lane);
+        if (l == 3) gemm_seg<26, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[DR3], RT0, 2 * wave, lane);
+        else gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[DR0 + l], RT0, 2 * wave, lane);
         __syncthreads();
         float* Rl = R + (size_t)(l - 1) * Mp * 256;
         // (the skip layer's per-lane test and ``save`` are compile-time in the epilogue: see deform_fwd_tile)
         auto epi = [&](auto SKIP, auto SAVE) {
-            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
-                const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+            for_quads_off(acc, qo, RT0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);      // (global row tile: the mask words are per 64-row tile)
                 if (decltype(SKIP)::value && col >= 204) {
                     lds_store_quad(aux, col - 204, row, v);          // skip: adjoint of the encoding part of layer 4's input
 #pragma unroll
@@ -234,10 +241,14 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
         __syncthreads();
     }
     {   // adjoint of the encoding input: += W_0^T r_0
-        f32x16 accA[1][1];
-        acc_zero(accA);
-        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[DR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 52) lds_add_quad(aux, col, row, v); });
+        // (a half tile: waves 0 / 1 take its one row tile, waves 2 / 3 have none)
+        if (!HALF || (wave >> 1) == 0) {
+            const int art = HALF ? RT0 : (wave >> 1);
+            f32x16 accA[1][1];
+            acc_zero(accA);
+            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[DR0], art, wave & 1, lane);
+            for_quads(accA, art, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 52) lds_add_quad(aux, col, row, v); });
+        }
     }
     __syncthreads();
     if (tid < 192) {   // g_o[j] = g_c[j] + sum_k adj[k] * d enc_k / d x_j   (position part of the encoding, observed-space x)
@@ -255,14 +266,22 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
             g += f * (as * co - ac * s);
             c2 += (f * f) * (as * s + ac * co);
         }
-        wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
-        wsb(a, WS_CURV)[(grow0 + row) * 3 + j] = c2;
+        if (!HALF || (row >> 5) == RT0) {
+            wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
+            wsb(a, WS_CURV)[(grow0 + row) * 3 + j] = c2;
+        }
     }
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// SDF network: value pass + reverse sweep.  Tile = 64 points.
-__device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
+// SDF network: value pass + reverse sweep.  Tile = 64 points.  HALF: one 32-row tile of a 64-row tile (see deform_vjp_tile): the
+// per-row stages still run on all 64 rows of the LDS tile (the other half's rows hold whatever its inputs hold and are never stored).
+template <bool HALF = false>
+__device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile_in) {
+    constexpr int RTC = HALF ? 1 : 2;
+    const int tile = HALF ? (tile_in >> 1) : tile_in;
+    const int RT0 = HALF ? (tile_in & 1) : 0;
+    auto own = [&](int row) { return !HALF || (row >> 5) == RT0; };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mainT = lds;
     float* aux = lds + MAIN_FLOATS;        // 56 rows: enc6(x_c) (40 used), later the adjoint of the encoding (40 used)
@@ -285,8 +304,10 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
             float x[3], t, d[3];
             load_point(a.src, row0 + tid, x, t, d);
             px[tid] = x[0]; px[64 + tid] = x[1]; px[128 + tid] = x[2];
-            float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
-            xc[0] = x[0]; xc[1] = x[1]; xc[2] = x[2];
+            if (own(tid)) {
+                float* xc = wsb(a, WS_XC) + (grow0 + tid) * 3;
+                xc[0] = x[0]; xc[1] = x[1]; xc[2] = x[2];
+            }
         }
     }
     __syncthreads();
@@ -296,18 +317,19 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
     if (save) {
         float* S0 = wsb(a, WS_S_S0);
         const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 40; k += 4) S0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+        if (own(r))
+            for (int k = c4; k < 40; k += 4) S0[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
     float* SACT = wsb(a, WS_S_ACT);
     // (bias requested a layer ahead: inside the epilogue the 16 quads reloaded it after every store -- 16 loads, their waits and nops)
-    const QuadOff<2> qo = quad_offsets<2>(0, 2 * wave, lane);
+    const QuadOff<RTC> qo = quad_offsets<RTC>(RT0, 2 * wave, lane);
     auto bias2 = [&](float(&b)[2], int l) {
         const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + l] + 64 * wave + (lane & 31);
         b[0] = bias[0]; b[1] = bias[32];
     };
-    auto epi = [&](f32x16(&acc)[2][2], int l, const float(&bc)[2]) {
+    auto epi = [&](f32x16(&acc)[RTC][2], int l, const float(&bc)[2]) {
         float* Sl = SACT + (size_t)l * Mp * 256;
-        for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+        for_quads_off(acc, qo, RT0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
             add_bias4(v, bc[ni]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = softplus100(v[i]);
@@ -318,35 +340,35 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
     float bc[2], bn[2];
     bias2(bn, 0);
     {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         bc[0] = bn[0]; bc[1] = bn[1];
         bias2(bn, 1);
-        gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF0], 0, 2 * wave, lane);
+        gemm_seg<5, RTC, 2>(acc, aux, a.packed + a.tb.segoff[SF0], RT0, 2 * wave, lane);
         epi(acc, 0, bc);
     }
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l <= 7; ++l) {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         bc[0] = bn[0]; bc[1] = bn[1];
         if (l < 7) bias2(bn, l + 1);
         const int seg = l <= 4 ? SF0 + l : SF0 + l + 1;
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);
-        if (l == 4) gemm_seg<5, 2, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], 0, 2 * wave, lane);
+        gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[seg], RT0, 2 * wave, lane);
+        if (l == 4) gemm_seg<5, RTC, 2>(acc, aux, a.packed + a.tb.segoff[SF4A], RT0, 2 * wave, lane);
         __syncthreads();
         epi(acc, l, bc);
         __syncthreads();
     }
     // last layer: 256 geometry features (MFMA) + sdf (row 0, VALU)
     if (color) {
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[SF8F], 0, 2 * wave, lane);
+        gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[SF8F], RT0, 2 * wave, lane);
         const float* bias = a.weff + a.tb.boff[NET_S * LAYERS + 8] + 1;
         float* feat = wsb(a, WS_FEAT);
-        for_quads(acc, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
+        for_quads(acc, RT0, 2 * wave, lane, [&](int row, int col, float(&v)[4]) {
             const float b = bias[col];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += b;
@@ -355,7 +377,7 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
     }
     smalln_partial<1>(mainT, a.weff + a.tb.woff[NET_S * LAYERS + 8], 256, red, tid);
     __syncthreads();
-    if (tid < 64) wsb(a, WS_SDF)[grow0 + tid] = smalln_reduce<1>(red, 0, tid) + a.weff[a.tb.boff[NET_S * LAYERS + 8]];
+    if (tid < 64 && own(tid)) wsb(a, WS_SDF)[grow0 + tid] = smalln_reduce<1>(red, 0, tid) + a.weff[a.tb.boff[NET_S * LAYERS + 8]];
 
     // ---- reverse sweep: rho_l = d sdf / d z_l ----
     float* RHO = wsb(a, WS_S_RHO);
@@ -363,8 +385,8 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         const float* w8 = a.weff + a.tb.woff[NET_S * LAYERS + 8];
         const float w8c[2] = {w8[64 * wave + (lane & 31)], w8[64 * wave + 32 + (lane & 31)]};
         auto rho7 = [&](auto SAVE) {
-            f32x16 dummy[2][2];
-            for_quads_off(dummy, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+            f32x16 dummy[RTC][2];
+            for_quads_off(dummy, qo, RT0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
                 const float4 t = *reinterpret_cast<const float4*>(mainT + off);
                 const float sv[4] = {t.x, t.y, t.z, t.w};
                 softplus100_grad_from_s4(sv, v);
@@ -380,21 +402,24 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
         const float* Sl = SACT + (size_t)(l - 1) * Mp * 256;                                      // s_l
-        f32x16 acc[2][2];
+        f32x16 acc[RTC][2];
         acc_zero(acc);
         const int seg = l <= 4 ? SR0 + l : SR0 + l + 1;
-        gemm_seg<32, 2, 2>(acc, mainT, a.packed + a.tb.segoff[seg], 0, 2 * wave, lane);       // adjoint of s_l
+        gemm_seg<32, RTC, 2>(acc, mainT, a.packed + a.tb.segoff[seg], RT0, 2 * wave, lane);       // adjoint of s_l
+        // (the 40-column adjoint of the encoding: one [32 x 32] block per wave of a full tile; waves 0 / 1 of a half tile take its row tile)
+        const bool has_a = !HALF || (wave >> 1) == 0;
+        const int art = HALF ? RT0 : (wave >> 1);
         f32x16 accA[1][1];
-        if (l == 4) {
+        if (l == 4 && has_a) {
             acc_zero(accA);
-            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], wave >> 1, wave & 1, lane);   // adjoint of the skip's encoding part
+            gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR4A], art, wave & 1, lane);   // adjoint of the skip's encoding part
         }
-        float S[16][4];                                          // all 16 quads requested at once: one memory round trip
-        prefetch_quads_f<2, 2>(S, Sl, grow0, 0, 2 * wave, lane);
+        float S[RTC * 8][4];                                     // all quads requested at once: one memory round trip
+        prefetch_quads_f<RTC, 2>(S, Sl, grow0, RT0, 2 * wave, lane);
         __syncthreads();
         auto repi = [&](auto SAVE) {
-            for_quads_off(acc, qo, 0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
-                const int qi = (((row >> 5) * 2 + ni) << 2) + ((row >> 3) & 3);
+            for_quads_off(acc, qo, RT0, 2 * wave, lane, [&](int row, int col, float(&v)[4], int off, int ni) {
+                const int qi = ((((row >> 5) - RT0) * 2 + ni) << 2) + ((row >> 3) & 3);
                 float dphi[4];
                 softplus100_grad_from_s4(S[qi], dphi);
 #pragma unroll
@@ -407,21 +432,23 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
             });
         };
         if (save) repi(std::true_type{}); else repi(std::false_type{});
-        if (l == 4)
-            for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
+        if (l == 4 && has_a)
+            for_quads(accA, art, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_store_quad(aux, col, row, v); });
         __syncthreads();
     }
-    {
+    if (!HALF || (wave >> 1) == 0) {
+        const int art = HALF ? RT0 : (wave >> 1);
         f32x16 accA[1][1];
         acc_zero(accA);
-        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], wave >> 1, wave & 1, lane);
-        for_quads(accA, wave >> 1, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_add_quad(aux, col, row, v); });
+        gemm_seg<32, 1, 1>(accA, mainT, a.packed + a.tb.segoff[SR0], art, wave & 1, lane);
+        for_quads(accA, art, wave & 1, lane, [&](int row, int col, float(&v)[4]) { if (col < 40) lds_add_quad(aux, col, row, v); });
     }
     __syncthreads();
     if (save) {
         float* AE = wsb(a, WS_S_ADJEPS);
         const int r = tid >> 2, c4 = tid & 3;
-        for (int k = c4; k < 40; k += 4) AE[(grow0 + r) * 64 + k] = aux[swz(k, r)];
+        if (own(r))
+            for (int k = c4; k < 40; k += 4) AE[(grow0 + r) * 64 + k] = aux[swz(k, r)];
     }
     if (tid < 192) {   // g_c[j] = sum_k adj_eps[k] * d enc_k / d x_j
         const int j = tid >> 6, row = tid & 63;
@@ -437,7 +464,7 @@ __device__ __forceinline__ void sdf_fwd_tile(const FwdArgs& a, const int tile) {
         gcv[j * 64 + row] = g;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 && own(tid)) {
         const size_t gp = grow0 + tid;
         const float g0 = gcv[tid], g1 = gcv[64 + tid], g2 = gcv[128 + tid];
         float* gc = wsb(a, WS_GC) + gp * 3;
