@@ -103,12 +103,13 @@ def kernel_macs(name, use_deform, executed=True):
     return nominal - (cut.get(name, 0) if executed else 0)
 
 
-def cpu_baseline(n_rays=1024, min_seconds=10.0, max_iters=40, threads=16, extra_256=True):
-    """The oracle (CPU restatement of the reference op sequence, torch-CPU fp32 + autograd) timed on this box's host cores
-    on a bounded sample of the same workload: full training steps at ``n_rays`` rays -- since round 4 the headline's own batch (1 024
-    rays x 64 samples; one warm-up + at least two timed steps, ~6 s each), with BASELINE config 1's 256-ray batch as an extra.  16 intra-op threads: at these tensor
-    sizes (8 192 points x 256 features per GEMM) torch-CPU is fastest there (measured 8/16/32/64/128 threads on the 2 x 64-core
-    host: 180 / 213 / 147 / 73 / 26 rays/s); ``cores`` reports the threads actually used."""
+def cpu_baseline(n_rays=1024, timed_steps=5, threads=16, extra_256=True):
+    """The oracle (CPU restatement of the reference op sequence, torch-CPU fp32 + autograd) timed on this box's host cores on a bounded
+    sample of the same workload, as SURVEY 8d asks: full training steps at ``n_rays`` rays -- the headline's own batch (1 024 rays x 64
+    samples) -- one warm-up + ``timed_steps`` (>= 5) timed steps, each timed on its own; ``value`` is taken at the MEDIAN step, min / max are in
+    the record (~11 s per step: ~70 s of the driver's run).  BASELINE config 1's 256-ray batch rides along as an extra.  16 intra-op threads:
+    at these tensor sizes (8 192 points x 256 features per GEMM) torch-CPU is fastest there (measured 8/16/32/64/128 threads on the 2 x
+    64-core host: 180 / 213 / 147 / 73 / 26 rays/s); ``cores`` reports the threads actually used."""
     import torch
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(min(threads, max(1, os.cpu_count() or threads)))
@@ -133,22 +134,24 @@ def cpu_baseline(n_rays=1024, min_seconds=10.0, max_iters=40, threads=16, extra_
         loss.backward()
         opt.step()
     step()
-    t0 = time.perf_counter()
-    it = 0
-    while it < max_iters and (time.perf_counter() - t0 < min_seconds or it < 2):
+    ts = []
+    for _ in range(max(1, int(timed_steps))):
+        t0 = time.perf_counter()
         step()
-        it += 1
-    dt = (time.perf_counter() - t0) / it
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
     cores = torch.get_num_threads()
     torch.set_num_threads(prev_threads)
     extra = None
     if extra_256 and n_rays != 256:       # round 3 reported this sample size (BASELINE config 1): kept as an extra so the series stays comparable
-        e = cpu_baseline(256, min_seconds=4.0, max_iters=12, threads=threads, extra_256=False)
+        e = cpu_baseline(256, timed_steps=3, threads=threads, extra_256=False)
         extra = dict(value=e["value"], n_rays=256, sample=e["sample"])
-    return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
-                sample=f"{it} full training steps (config 2 networks and loss) of the CPU oracle at {n_rays} rays x 64 samples "
-                       f"({'the batch the headline is measured on' if n_rays == 1024 else ('BASELINE config 1: the 256-ray batch' if n_rays == 256 else 'a sample of the 1024-ray batch')}), "
-                       f"torch-CPU fp32 + autograd, {dt:.2f} s/step",
+    what = ("the batch the headline is measured on" if n_rays == 1024 else
+            ("BASELINE config 1: the 256-ray batch" if n_rays == 256 else "a sample of the 1024-ray batch"))
+    return dict(value=n_rays / med, unit="rays/s", cores=cores, kind="port", steps=len(ts), s_per_step_median=med, s_per_step_min=min(ts),
+                s_per_step_max=max(ts), value_min=n_rays / max(ts), value_max=n_rays / min(ts),
+                sample=f"1 warm-up + {len(ts)} timed steps, median: full training steps (config 2 networks and loss) of the CPU oracle at {n_rays} "
+                       f"rays x 64 samples ({what}), torch-CPU fp32 + autograd, {med:.2f} s/step (min {min(ts):.2f}, max {max(ts):.2f})",
                 config=dict(n_rays=n_rays, samples_per_ray=64, threads=cores), at_256_rays=extra,
                 reference_in_build_container="profiles/reference_cpu.json: the reference itself (imported unmodified), 8 vCPU build container")
 
@@ -190,6 +193,81 @@ def pmc_rates(pm, avg_launch_ms):
         return None, None, ("withheld: the committed counters (%s) and the live launch time disagree (%.2f GHz, %.0f GB/s): different "
                             "build or launch mix" % (pm["source"], ghz, gbps))
     return gbps, ghz, None
+
+
+# ---- algorithmic HBM bytes of the stream-heavy kernels -----------------------------------------------------------------------
+# Per POINT and body, from the workspace layout (csrc/workspace.h) and the loads / stores the tile bodies issue (point_fwd_bodies.h,
+# point_bwd_bodies.h, wgrad.hip): every saved stack is fp32 [layers][M][256] = 1 024 B per layer and point ("K" below); a body's figure is
+# each stack it must write once + each stack it must read once (+ the re-reads its two-sweep STRUCTURE implies, named below).  Small
+# per-point vectors (3 - 64 floats) are included where they exceed 100 B.
+_K = 1024
+HBM_BYTES_PER_POINT = {
+    # deformation value + tangent rows (2 rows per point): u_1..u_8 (16 K), encoding rows U0 (2 x 64 floats), mask words (8 x 32 B), x_c | J d
+    "deform_fwd": 16 * _K + 512 + 256 + 24,
+    # VJP sweep: r_0..r_7 (8 K), mask words (8 x 64 B: a 64-point tile reads both 32-point producers' words), g_c in, g_o | curvature out
+    "deform_vjp": 8 * _K + 512 + 36,
+    # SDF value pass + reverse sweep: s_1..s_8 written (8 K) and s_1..s_7 read back by the reverse sweep (7 K: the two-sweep structure),
+    # rho_0..rho_7 (8 K), enc(x_c) and its adjoint (2 x 64 floats), the 256 geometry features (1 K, colour points only)
+    "sdf_fwd": 8 * _K + 7 * _K + 8 * _K + 512 + 28,
+    "sdf_fwd_feat": _K,
+    # colour: h_1..h_8 (8 K), features read at layer 0 and again at the skip layer (2 K), the 93-wide small input written (128 floats) and
+    # re-read at the skip layer (96 floats), mask words (8 x 32 B), x_c | g_c | J d in, rgb out
+    "color_fwd": 8 * _K + 2 * _K + 512 + 384 + 256 + 48,
+    # colour reverse sweep: y_0..y_7 (8 K) + y_8 (4 floats), featbar written at layer 0 and read-modified-written at the skip layer (3 K),
+    # the small part's adjoint likewise (3 x 128 floats), mask words, three 3-vectors out
+    "color_bwd": 8 * _K + 16 + 3 * _K + 1536 + 256 + 60,
+    # deformation tangent sweep along gbar_o: tau_1..tau_8 (8 K) + its encoding tangent (64 floats), mask words, gbar_o in, J gbar_o out
+    "deform_tan": 8 * _K + 256 + 512 + 24,
+    # SDF backward = tangent sweep (reads s_l, rho_l; writes tau_l, zeta_l: 4 x 8 K) + reverse sweep (reads s_l AGAIN and zeta_l, writes
+    # zbar_l in place: 3 x 8 K): the 7 x 8 K = 56 KiB floor of the two-sweep structure (DEAD_ENDS A9); tau_0, adj_eps (2 x 64 floats)
+    "sdf_bwd": 7 * 8 * _K + 512 + 60,
+    "sdf_bwd_feat": _K,
+    # deformation reverse sweep (2 rows per point): a_0..a_7 (16 K) + a_8 (2 x 4 floats), mask words, seeds in
+    "deform_bwd": 16 * _K + 32 + 256 + 24,
+    # weight gradients: every (layer input X, adjoint dA) pair read ONCE.  deform: value + tangent rows (u 16 K + U0 512 | a 16 K + a_8 32)
+    # and the VJP path's pair (tau 8 K + tau_0 256 | r 8 K); sdf: (s 8 K + enc 256 | zbar 8 K) and (tau 8 K + tau_0 256 | rho 8 K) + featbar
+    # (1 K, colour points); colour: (h 8 K + features 2 x 1 K + small part 2 x 96 floats | y 8 K + y_8 16)
+    "wgrad_deform": 16 * _K + 512 + 16 * _K + 32 + 8 * _K + 256 + 8 * _K + 12,
+    "wgrad_sdf": 8 * _K + 256 + 8 * _K + 8 * _K + 256 + 8 * _K,
+    "wgrad_sdf_feat": _K,
+    "wgrad_color": 8 * _K + 2 * _K + 768 + 8 * _K + 16,
+}
+_WG_NOTE = ("each [256 x 128] task reads its dA rows in full, so the two k-block tasks of a row chunk read dA twice: once more than the "
+            "algorithmic count (+8 KiB per point and pair).  Their block ids are 8 apart (same XCD, back to back: wgrad.hip wg_decode) so that the "
+            "second read can hit that XCD's L2")
+
+
+def hbm_accounting(P, T):
+    """Algorithmic HBM bytes per launch of the headline step's stream-heavy symbols (P = rays x samples colour points, T = the colour-less
+    auxiliary points riding in the same launches) beside the committed PMC traffic of the same symbol, and their ratio."""
+    B = HBM_BYTES_PER_POINT
+    tail_fwd = B["sdf_fwd"] + B["deform_vjp"]          # the tail's [sdf + vjp] tiles ride in the main deformation launch (point_fwd.hip)
+    tail_bwd = B["deform_tan"] + B["sdf_bwd"]          # the tail's [tan + sdf_bwd] tiles ride in the main deformation reverse sweep
+    comp = {
+        "k_deform_fwd": (P * B["deform_fwd"] + T * tail_fwd, "P x deform_fwd + T x (sdf_fwd + deform_vjp): the tail's dependent stages ride in this launch", None),
+        "k_sdf_fwd": (P * (B["sdf_fwd"] + B["sdf_fwd_feat"]), "P x sdf_fwd (incl. the geometry features)", None),
+        "k_color_fwd": (P * B["color_fwd"], "P x color_fwd", None),
+        "k_deform_vjp": (P * B["deform_vjp"], "P x deform_vjp", None),
+        "k_color_bwd": (P * B["color_bwd"], "P x color_bwd", None),
+        "k_deform_tan": (P * B["deform_tan"], "P x deform_tan", None),
+        "k_sdf_bwd": (P * (B["sdf_bwd"] + B["sdf_bwd_feat"]), "P x sdf_bwd (incl. featbar)", None),
+        "k_deform_bwd": (P * B["deform_bwd"] + T * tail_bwd, "P x deform_bwd + T x (deform_tan + sdf_bwd): the tail's dependent stages ride in this launch", None),
+        "k_wgrad[deform]": ((P + T) * B["wgrad_deform"], "(P + T) x wgrad_deform", _WG_NOTE + "; the row-major deformation stacks mostly do"),
+        "k_wgrad[sdf]": ((P + T) * B["wgrad_sdf"] + P * B["wgrad_sdf_feat"], "(P + T) x wgrad_sdf + P x featbar",
+                         _WG_NOTE + "; for the fragment-ordered SDF stacks it does not: both dA stacks (zbar, rho) come from HBM twice, "
+                         "+16 KiB per point = the whole excess"),
+        "k_wgrad[color]": (P * B["wgrad_color"], "P x wgrad_color", _WG_NOTE + "; here it does not: +8 KiB per point = the whole excess"),
+    }
+    out = []
+    for sym, (alg, what, note) in comp.items():
+        pm = pmc_info(sym)
+        rows = [r for r in (pm["rows"] if pm else []) if r["grid_threads"] >= 131072]      # the main launch of the symbol (not its small pieces)
+        meas = (sum(r["hbm_bytes"] * r["launches"] for r in rows) / sum(r["launches"] for r in rows)) if rows else None
+        out.append(dict(kernel=sym, algorithmic_bytes_per_launch=int(alg), composition=what,
+                        pmc_hbm_bytes_per_launch=meas, pmc_source=pm["source"] if pm else None,
+                        ratio=round(meas / alg, 3) if meas else None, per_point_algorithmic_bytes=round(alg / (P + T if "P + T" in what or "T x" in what else P), 1),
+                        explanation=note))
+    return out
 
 
 def pmc_traffic(symbol):
@@ -799,7 +877,7 @@ def run_extras(ctx, args, partial):
                                      workload=wl.describe(), n_gpus=ctx.world, roofline=wl.roofline(m, full=False),
                                      kernel_ms_per_step=m["timing"].get("per_step_ms"), host_issue_ms=m["host_issue_ms"],
                                      sum_timed_kernel_ms=m["sum_timed_kernel_ms"],
-                                     captured=(bool((wl.renderer.__dict__.get("_fwd_graph") or {}).get("graph")) if wl.mode == "forward" else None),
+                                     captured=(bool((getattr(wl.renderer, "_fwd_graph", None) or {}).get("graph")) if wl.mode == "forward" else None),
                                      seconds=None)
         except Exception as e:      # an extra must never cost the headline line
             ok = False
@@ -829,7 +907,7 @@ def main():
                     help="skip the extra early-exit timing and the extras (profiling runs: every launch of the process then belongs to the "
                          "headline workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (forward / split precision / cfg3 / cfg4 / cfg5 frame)")
-    ap.add_argument("--extras-timeout", type=float, default=240.0, help="watchdog: seconds the extras may take before the line is printed without them")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="watchdog: seconds the extras may take before the line is printed without them")
     ap.add_argument("--split-precision", action="store_true",
                     help="OPT-IN extra line, never the headline: large no-grad SDF queries and the weight-gradient GEMMs on the bf16 matrix "
                          "pipes with exact 3-way operand splitting (csrc/query_x3.hip, wgrad.hip); everything else stays fp32 MFMA")
@@ -934,7 +1012,13 @@ def main():
                    host_note="host_issue_ms: CPU time to enqueue one step into an empty queue (median of 5); sum_timed_kernel_ms: the MLP chain / "
                              "query / weight-gradient launches of one step (HIP events; the two front-end chains of a training step overlap)",
                    roofline=wl.roofline(m), kernel_ms_per_step=timing.get("per_step_ms"), kernel_symbols=timing.get("symbols"),
-                   kernel_launch_groups=timing.get("launch_groups"), cpu_baseline=None, extras=None)
+                   kernel_launch_groups=timing.get("launch_groups"),
+                   hbm_accounting=(hbm_accounting(wl.n_rays * wl.S, 3 * wl.n_rays) if (args.config == 2 and mode == "train" and not args.rays
+                                                                                       and not args.split_precision and args.schedule == "fused") else None),
+                   hbm_accounting_note="algorithmic HBM bytes per launch (bench.py HBM_BYTES_PER_POINT: every saved stack written once / read once, "
+                                       "per point, x the points of the launch) beside the rocprofv3 traffic of the same symbol from the committed PMC "
+                                       "summary (FETCH_SIZE x 2 + WRITE_SIZE); ratio = measured / algorithmic",
+                   cpu_baseline=None, extras=None)
     headline_is_default = args.config == 2 and mode == "train" and not args.split_precision and not args.rays
     want_extras = headline_is_default and not (args.no_extras or args.headline_only)
     wl.close()

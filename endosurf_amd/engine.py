@@ -59,6 +59,7 @@ class Engine:
         self._arena, self._arena_off, self._arena_on = None, 0, False
         self._ones1 = None
         self._rng_calls = 0
+        self._rng_step_calls = 0          # draws of the current step with a device-resident step counter (uniform)
         # set by a data-parallel Trainer with overlap_allreduce: called as hook(stage, dweff) behind each weight-gradient launch of a step
         self.wgrad_stage_hook = None
         self._grad_pipeline = None          # state of a pipelined data-parallel step (trainer.Trainer._train_step_pipelined)
@@ -110,6 +111,7 @@ class Engine:
             self._arena = self.empty(need)
         check(self.lib.es_zero(ptr(self._arena), 4 * self._arena.numel(), self.st()), "es_zero")
         self._arena_off, self._arena_on = 0, True
+        self._rng_step_calls = 0
 
     def arena_end(self):
         self._arena_on = False
@@ -128,9 +130,11 @@ class Engine:
         out = self.empty(int(n))
         seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         if step_dev is not None:
-            # graph-mode steps (the two eager warm-up calls and every replay) draw from subsequences 2^63 + step counter: a space
-            # disjoint from the eager steps' call index below, so that mixing train_step and train_step_graph never repeats a stream
-            sub = 1 << 63
+            # graph-mode steps (the two eager warm-up calls and every replay) draw from subsequences 2^63 + (k << 40) + step counter, k = the
+            # index of the call within its step (reset by arena_begin): a space disjoint from the eager steps' call index below, so that
+            # mixing train_step and train_step_graph never repeats a stream, and two draws of one step never share one
+            sub = (1 << 63) + (self._rng_step_calls << 40)
+            self._rng_step_calls += 1
         else:
             sub = self._rng_calls
             self._rng_calls += 1

@@ -444,7 +444,8 @@ class _PackFn(torch.autograd.Function):
         if dweff is None:
             return (None, None, *[None for _ in ctx.slots])
         pipe = getattr(ctx.eng, "_grad_pipeline", None)
-        if pipe is not None and pipe.get("dflat") is not None and pipe.get("dweff_ptr") == dweff.data_ptr():
+        if pipe is not None and pipe.get("dflat") is not None and pipe.get("dweff_ptr") == (dweff.data_ptr(), dweff._version):
+            pipe["adopted"] = True
             # a pipelined data-parallel step (trainer.Trainer overlap_allreduce): the hooks behind the weight-gradient launches have
             # already written (and are all-reducing) the finished layers' slices; the rest -- whatever the hooks left -- is done here
             dflat = pipe["dflat"]
@@ -485,6 +486,7 @@ class _PointEvalFn(torch.autograd.Function):
         pctx = eng.point_forward(pts, weff, packed, flags, fp32_only=x_in is not None)
         ctx.pctx, ctx.eng, ctx.weff, ctx.packed = pctx, eng, weff, packed
         ctx.pts, ctx.flags = pts, flags
+        ctx.set_materialize_grads(False)
         ctx.wrt_x = x_in is not None
         ctx.x_shape = tuple(x_in.shape) if x_in is not None else None
         ctx.x_dtype = x_in.dtype if x_in is not None else None
@@ -498,7 +500,13 @@ class _PointEvalFn(torch.autograd.Function):
         eng, pctx = ctx.eng, ctx.pctx
         if not (ctx.flags & _lib.PF_SAVE):
             raise RuntimeError("point evaluation was run without PF_SAVE; cannot backpropagate")
+        if ctx.wrt_x and d_go is None and d_rgb is None and not ctx.needs_input_grad[0]:
+            # the reference's first pass, autograd.grad(sdf, x, create_graph=True) (endosurf.py:585-600): only the adjoint of the POINTS is
+            # asked for, and through g_o alone that is identically zero (d sdf / d x = g_o is attached by the caller) -- no launch, and the
+            # workspace stays whole for the loss.backward() that follows
+            return None, None, None, None, None, torch.zeros(ctx.x_shape, device=eng.device, dtype=ctx.x_dtype)
         if pctx is None:
+            # (the re-evaluation reads ctx.weff / ctx.packed: the buffers of THIS forward, which later parameter updates never touch)
             # second backward through the same node (retain_graph / the reference's autograd.grad(sdf, x, create_graph=True) followed by
             # loss.backward(): with point-differentiable outputs the first pass already went through here).  The backward kernels consume
             # the workspace, so the forward is evaluated again -- same kernels, same inputs, same values.
@@ -507,7 +515,10 @@ class _PointEvalFn(torch.autograd.Function):
         dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, d_go, d_rgb)
         xbar = None
         if ctx.wrt_x and ctx.needs_input_grad[5]:
-            xbar = eng.point_input_adjoint(pctx, ctx.weff, ctx.packed, d_sdf, d_go).reshape(ctx.x_shape).to(ctx.x_dtype)
+            if d_go is None:          # through g_o alone the points' adjoint is zero (see above): no VJP launch
+                xbar = torch.zeros(ctx.x_shape, device=eng.device, dtype=ctx.x_dtype)
+            else:
+                xbar = eng.point_input_adjoint(pctx, ctx.weff, ctx.packed, d_sdf, d_go).reshape(ctx.x_shape).to(ctx.x_dtype)
         ctx.pctx = None
         return dweff, None, None, None, None, xbar
 
@@ -901,14 +912,24 @@ class EndoSurfRenderer(nn.Module):
         perturb = self.perturb if kwargs.get("perturb_overwrite") is None else bool(kwargs["perturb_overwrite"])
         upsample = iter_step >= self.important_begin_iter and self.n_importance > 0
         weff, _ = self._weights()
-        key = (tuple(rays.shape), bool(perturb), bool(upsample), bool(kwargs.get("eval", False)), weff.data_ptr(),
-               tuple(p._version for p in self.parameters()), self.model._epoch, bool(eng.split_precision), int(eng.x3_query_min),
-               int(eng.x3_infer_min), bool(eng.deterministic), self.n_samples, self.n_importance, self.up_sample_steps, self.use_deform)
-        g = self.__dict__.get("_fwd_graph")
+        # one slot per call SHAPE (ray count, sampling mode, kernel switches), at most three of them (least recently used goes): the
+        # reference's eval loop alternates full chunks with one shorter last chunk per image, and a single slot made every image pay
+        # eager + capture + instantiate again.  A slot holds the graph's private memory pool (the point workspace of one chunk: ~0.4 GB at
+        # 2 048 rays without saving) until it is evicted, the weights change (the next call of that shape re-captures) or a grad-enabled
+        # render starts (release_forward_graphs).
+        skey = (tuple(rays.shape), bool(perturb), bool(upsample), bool(kwargs.get("eval", False)), bool(eng.split_precision), int(eng.x3_query_min),
+                int(eng.x3_infer_min), bool(eng.deterministic), self.n_samples, self.n_importance, self.up_sample_steps, self.use_deform)
+        key = (weff.data_ptr(), tuple(p._version for p in self.parameters()), self.model._epoch)
+        slots = self.__dict__.setdefault("_fwd_graphs", {})
+        g = slots.pop(skey, None)
         if g is None or g["key"] != key:
-            # first call of this key: eager (it is also the warm-up a capture needs: lazy initialisation, allocator); the next one captures
-            self.__dict__["_fwd_graph"] = dict(key=key, graph=None)
+            # first call of this shape with these weights: eager (it is also the warm-up a capture needs: lazy initialisation, allocator);
+            # the next one captures
+            slots[skey] = dict(key=key, graph=None)
+            while len(slots) > 3:
+                slots.pop(next(iter(slots)))
             return None
+        slots[skey] = g          # (most recently used last)
         cos = self.get_cos_anneal_ratio(iter_step)
         if g["graph"] is False:          # a capture of this key failed before: stay eager
             return None
@@ -946,6 +967,17 @@ class EndoSurfRenderer(nn.Module):
             out[k] = flat[off:off + n].view(shape)
             off += n
         return out
+
+    @property
+    def _fwd_graph(self):
+        """The most recently used slot of the captured no-grad forwards (None: none yet)."""
+        slots = self.__dict__.get("_fwd_graphs")
+        return slots[next(reversed(slots))] if slots else None
+
+    def release_forward_graphs(self):
+        """Drop the captured no-grad forwards (and with them their private memory pools).  Called when a grad-enabled render starts:
+        training needs the memory, and the weights are about to change anyway."""
+        self.__dict__.pop("_fwd_graphs", None)
 
     @_on_device
     def sample_z(self, rays, iter_step=0, perturb_overwrite=None, u_perturb=None, racing=False):
@@ -1118,6 +1150,8 @@ class EndoSurfRenderer(nn.Module):
         trainer's step repeats the same three calls); None when nothing was asked for or the render cannot host one."""
         if not (flags & _lib.PF_SAVE):
             return None
+        if self.__dict__.get("_fwd_graphs"):
+            self.release_forward_graphs()
         demand, self._aux_demand = getattr(self, "_aux_demand", 0), 0
         eng = self.engine
         if demand <= 0 or chunk or P_ <= 0 or P_ % 64 or eng.split_precision or torch.cuda.is_current_stream_capturing():

@@ -176,6 +176,12 @@ class _LossFn(torch.autograd.Function):
         return (gc, gd, ge.reshape(ctx.eik_shape), gs, gg, None, None, None, None, None, None, None, None, None, None)
 
 
+def _lib_flags_save(renderer) -> int:
+    """The point-evaluation flags of a grad-enabled render of this renderer (what its workspace budget is computed for)."""
+    from . import _lib
+    return (_lib.PF_DEFORM if renderer.use_deform else 0) | _lib.PF_SAVE
+
+
 def lr_factor(it: int, n_iter: int = 100000, warm_up_end: int = 5000, alpha: float = 0.05) -> float:
     """update_learning_rate (trainer_endosurf.py:183-203)."""
     if it < warm_up_end:
@@ -577,7 +583,9 @@ class Trainer:
         pipe = eng._grad_pipeline
         plan = self._bucket_plan()
         if pipe["dflat"] is None:
-            pipe["dflat"], pipe["dweff_ptr"], pipe["remaining"] = eng.zeros(eng.n_param), dweff.data_ptr(), plan["remaining"]
+            # the tag _PackFn.backward recognises the hooks' buffer by: the tensor's address AND its version counter (autograd sums the
+            # gradients of several consumers of weff, possibly in place into the first one: same address, other contents)
+            pipe["dflat"], pipe["dweff_ptr"], pipe["remaining"] = eng.zeros(eng.n_param), (dweff.data_ptr(), dweff._version), plan["remaining"]
         job = plan["A"] if stage == _lib.BWD_WGRAD_DEFORM else (plan["B"] if stage == _lib.BWD_WGRAD_SDF else None)
         if job is None:
             return
@@ -590,38 +598,60 @@ class Trainer:
             eng.weightnorm_backward_layers(self.renderer.model._flat, dweff, pipe["dflat"], first, n)
             allreduce_flat(pipe["dflat"][a:b], group=self.group, force=self.force_collective)
 
+    def _pipeline_applies(self, batch) -> bool:
+        """The bucket pipeline needs the render to be the ONLY consumer of the effective weights in the step (the hooks hand slices of
+        ITS gradient to the side stream): the fused schedule, auxiliary points riding in the render launches (tile-aligned sample count),
+        no ray chunking, the fp32 chain.  Decided from the configuration and the batch SHAPE before the step, so that every rank of a
+        job takes the same branch (= issues the same sequence of collectives)."""
+        r, eng = self.renderer, self.renderer.engine
+        if self.loss_fn is not compute_loss_fused and getattr(self.loss_fn, "func", None) is not compute_loss_fused:
+            return False
+        N = batch["rays"].shape[0]
+        up = r.n_importance if r.n_importance > 0 else 0          # (important_begin_iter > step only makes the sample count smaller)
+        for S in {r.n_samples, r.n_samples + up}:
+            if N == 0 or (N * S) % 64:
+                return False
+        f = (_lib_flags_save(r))
+        if r._chunk_rays(N, r.n_samples + up, f):
+            return False
+        return not (eng.split_precision and eng.x3_train_chain)
+
     def _train_step_pipelined(self, batch, global_step: int, u_perturb=None, u_neigh=None):
         from .parallel import allreduce_flat
         eng = self.renderer.engine
         if self._ar_stream is None:
             self._ar_stream = torch.cuda.Stream(device=eng.device)
-        eng._grad_pipeline = dict(dflat=None, dweff_ptr=None, remaining=None)
+        eng._grad_pipeline = dict(dflat=None, dweff_ptr=None, remaining=None, adopted=False)
         eng.wgrad_stage_hook = self._pipeline_hook
         try:
             loss, terms, ret = self._step_body(batch, global_step, u_perturb, u_neigh)
         finally:
             eng.wgrad_stage_hook = None
             pipe, eng._grad_pipeline = eng._grad_pipeline, None
-        g = self.optimizer.flat_grad(include_variance=True)
-        world = 1
-        if pipe["dflat"] is not None and g.data_ptr() == pipe["dflat"].data_ptr():
-            ev = self.allreduce_events
-            if ev is not None:
-                ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-                ev[-1][0].record()
-            for a, b in self._bucket_plan()["C"]:
-                world = allreduce_flat(g[a:b], group=self.group, force=self.force_collective)
+            # whatever happened, nothing of this step may still be running on the side stream when its buffers (slices of the step
+            # arena) are reused
             torch.cuda.current_stream(eng.device).wait_stream(self._ar_stream)
-            if ev is not None:
-                ev[-1][1].record()
-            self.pipelined_steps += 1
-        else:       # the step did not go through the staged backward (chunked render, split-precision chain ...): one bucket
-            world = allreduce_flat(g, group=self.group, force=self.force_collective)
+        if pipe["dflat"] is None or not pipe["adopted"]:
+            # _pipeline_applies said the render is the only consumer of weff, yet the weight-norm backward did not receive the buffer the
+            # hooks worked on: the ranks' collective sequences can no longer be trusted to match
+            raise RuntimeError("overlap_allreduce: the staged backward and the weight-norm backward disagree about the gradient buffer "
+                               "(a second consumer of the effective weights in this step?); run this configuration with overlap_allreduce=False")
+        g = self.optimizer.flat_grad(include_variance=True)
+        ev = self.allreduce_events
+        if ev is not None:
+            ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            ev[-1][0].record()
+        world = 1
+        for a, b in self._bucket_plan()["C"]:
+            world = allreduce_flat(g[a:b], group=self.group, force=self.force_collective)
+        if ev is not None:
+            ev[-1][1].record()
+        self.pipelined_steps += 1
         self.optimizer.step(grad=g, grad_scale=1.0 / world, variance_in_grad=True)
         return loss.detach(), terms, ret
 
     def _train_step(self, batch, global_step: int, u_perturb=None, u_neigh=None):
-        if self.overlap_allreduce and self.data_parallel and isinstance(self.optimizer, FlatAdam):
+        if self.overlap_allreduce and self.data_parallel and isinstance(self.optimizer, FlatAdam) and self._pipeline_applies(batch):
             return self._train_step_pipelined(batch, global_step, u_perturb, u_neigh)
         loss, terms, ret = self._step_body(batch, global_step, u_perturb, u_neigh)
         if isinstance(self.optimizer, FlatAdam):

@@ -111,7 +111,17 @@ def test_bench_default_line_carries_extras():
     d = json.loads(lines[0])
     assert d["config"]["baseline_config"] == 2 and d["dtype"] == "f32" and d["n_gpus"] == 1 and d["ranks_seen_by_collective"] is None
     ex = d["extras"]
-    assert set(ex) == {"forward", "split_precision_train", "cfg3", "cfg4", "cfg5_frame"}, ex.keys()
+    assert set(ex) == {"reference_call_sequence", "forward", "split_precision_train", "cfg3", "cfg4", "cfg5_frame"}, ex.keys()
+    # the reference trainer's own loop through the drop-in: without and with its logging traffic; from its second step
+    # on the two auxiliary calls' points live in the render's workspace (3 x 1024 rows)
+    rs = ex.pop("reference_call_sequence")
+    assert "error" not in rs, rs
+    for k in ("plain", "with_reference_logging"):
+        e = rs[k]
+        assert e["ms_per_step"] > 0 and e["value"] > 0 and e["sum_timed_kernel_ms"] > 0 and e["aux_rows_in_render_workspace"] == 3072, (k, e)
+        assert e["with_early_exit"]["ms_per_step"] > 0
+    assert rs["plain"]["host_syncs_per_step"] == 1 and rs["with_reference_logging"]["host_syncs_per_step"] == 14
+    assert rs["plain"]["host_issue_ms"] < rs["plain"]["ms_per_step"] < 1.5 * d["ms_per_step"]
     for k, e in ex.items():
         assert "error" not in e, (k, e)
         assert e["value"] > 0 and e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < 1 and e["roofline"]["end_to_end"]["frac"] > 0, (k, e)

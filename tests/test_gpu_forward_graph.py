@@ -32,7 +32,7 @@ def test_captured_forward_is_bit_identical_to_the_eager_one(use_deform):
         ea = e(a, iter_step=20000, perturb_overwrite=False)
         eb = e(b, iter_step=20000, perturb_overwrite=False)
         ea3 = e(a, iter_step=30000, perturb_overwrite=False)
-        assert e.__dict__.get("_fwd_graph") is None
+        assert e._fwd_graph is None
     assert set(first) == set(second) == set(ea) == set(KEYS)
     for k in KEYS:
         assert second[k].shape == eb[k].shape and second[k].dtype == eb[k].dtype, k
@@ -77,14 +77,37 @@ def test_captured_forward_stands_down():
     u = torch.rand(64, 1, device="cuda")
     with torch.no_grad():
         r(a, iter_step=1, u_perturb=u); r(a, iter_step=1, u_perturb=u)
-    assert r.__dict__.get("_fwd_graph") is None
+    assert r._fwd_graph is None
     r(a, iter_step=1); r(a, iter_step=1)                                      # grad enabled
-    assert r.__dict__.get("_fwd_graph") is None
+    assert r._fwd_graph is None
     r.engine.timing_enable(True)
     try:
         with torch.no_grad():
             r(a, iter_step=1); r(a, iter_step=1)
-        assert r.__dict__.get("_fwd_graph") is None
+        assert r._fwd_graph is None
     finally:
         r.engine.timing_drain()
         r.engine.timing_enable(False)
+
+
+def test_captured_forward_keeps_a_slot_per_shape():
+    """The eval loop's pattern (trainer_endosurf.py:221-240): full chunks, one shorter last chunk, next image: both shapes stay captured
+    (at most three slots); a grad-enabled render releases them."""
+    r = renderer_for(21, "trained", True)
+    full, last = _rays(256, 5), _rays(96, 6)
+    with torch.no_grad():
+        for _ in range(2):
+            r(full, iter_step=7, perturb_overwrite=False)
+            r(last, iter_step=7, perturb_overwrite=False)
+        slots = r.__dict__["_fwd_graphs"]
+        assert len(slots) == 2 and all(s["graph"] is not None for s in slots.values())
+        graphs = [s["graph"] for s in slots.values()]
+        a = r(full, iter_step=7, perturb_overwrite=False)
+        b = r(last, iter_step=7, perturb_overwrite=False)
+        assert [s["graph"] for s in r.__dict__["_fwd_graphs"].values()] == graphs          # replays, no re-capture
+        for n in (32, 64, 128):                                                           # three more shapes: the oldest slots go
+            r(_rays(n), iter_step=7, perturb_overwrite=False)
+        assert len(r.__dict__["_fwd_graphs"]) == 3
+    assert a["color_map"].shape[0] == 256 and b["color_map"].shape[0] == 96
+    r(full, iter_step=7)["color_map"].sum().backward()                                    # grad-enabled render: the slots are released
+    assert r._fwd_graph is None
