@@ -21,7 +21,7 @@
 
 namespace es {
 
-#ifdef ES_PROFILE_BWD        // dev builds only: cycle stamps of block 0 / thread 0 inside sdf_bwd_tile (tools/bwd_profile.py)
+#ifdef ES_PROFILE_BWD        // dev builds only: cycle stamps of block 0 / thread 0 inside sdf_bwd_tile (tools/dev/bwd_profile.py)
 __device__ long long b_prof[256];
 extern "C" int es_debug_b_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(b_prof), sizeof(long long) * (n < 256 ? n : 256)); }
 #endif

@@ -10,7 +10,7 @@
 
 namespace es {
 
-#ifdef ES_PROFILE_BWD        // dev builds only: cycle stamps of block 0 / thread 0 inside sdf_bwd_tile (tools/bwd_profile.py)
+#ifdef ES_PROFILE_BWD        // dev builds only: cycle stamps of block 0 / thread 0 inside sdf_bwd_tile (tools/dev/bwd_profile.py)
 extern __device__ long long b_prof[256];
 #define B_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) b_prof[i] = __builtin_readcyclecounter(); } while (0)
 #else

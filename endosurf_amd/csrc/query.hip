@@ -13,7 +13,7 @@
 
 namespace es {
 
-#ifdef ES_PROFILE_QUERY      // dev builds only: cycle stamps of block 0 / thread 0 at the phase boundaries (tools/q_profile.py)
+#ifdef ES_PROFILE_QUERY      // dev builds only: cycle stamps of block 0 / thread 0 at the phase boundaries (tools/dev/q_profile.py)
 __device__ long long q_prof[64];
 #define Q_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) q_prof[i] = __builtin_readcyclecounter(); } while (0)
 extern "C" int es_debug_q_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_prof), sizeof(long long) * (n < 64 ? n : 64)); }
@@ -175,10 +175,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
 }
 
 int query_sdf16(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st);
-#ifdef ES_DEV_SWITCHES      // query_t.hip: the transposed formulation, dev builds only
-int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
-                const int* ray_done, bool half, int dbg);
-#endif
 
 // tile_points: 0 = chosen by the batch size (<= 9 216 points: the 16-point tiles of query16.hip -- the up-sampling queries of 1 024 rays and
 // the secant iterations are latency-bound on their own; <= 16 384: 32-point tiles, fewer than one 64-point tile per CU otherwise; above: 64),
@@ -189,18 +185,9 @@ int query_sdf_t(const PointSrc& src, const float* packed, const float* weff, flo
 int query_sdf(const PointSrc& src, const float* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st,
               int ld_out, const int* ray_done, int tile_points) {
     int tp = tile_points ? tile_points : (src.M <= 9216 ? 16 : (src.M <= 16384 ? 32 : 64));
-#ifdef ES_DEV_SWITCHES      // dev builds only (-DES_DEV_SWITCHES): A/B runs of the tile-height threshold
-    static const int q16_env = getenv("ES_Q16_MAX") ? atoi(getenv("ES_Q16_MAX")) : 0;
-    if (q16_env > 0 && !tile_points) tp = src.M <= q16_env ? 16 : tp;
-#endif
     if (tp == 16 && !(ld_out == 0 && ray_done == nullptr)) tp = 32;      // (the 16-point kernel writes flat outputs only)
     if (src.M > 0 && tp == 16)
         return query_sdf16(src, packed, weff, sdf_out, use_deform, st);   // latency-bound batches
-#ifdef ES_DEV_SWITCHES      // dev builds only: A/B of the transposed formulation (query_t.hip): ES_QT=1 both tile heights, 2 = 64-point tiles only
-    static const int qt_env = getenv("ES_QT") ? atoi(getenv("ES_QT")) : 0;
-    if (qt_env == 1 || qt_env == 3 || (qt_env == 2 && tp == 64)) return query_sdf_t(src, packed, weff, sdf_out, use_deform, st, ld_out, ray_done, tp == 32, qt_env == 3);
-    if (qt_env >= 100) return query_sdf_t(src, packed, weff, sdf_out, use_deform, st, ld_out, ray_done, tp == 32, qt_env - 100);
-#endif
     static DeviceOnce attr_done;
     if (attr_done.first()) {
         if (int e = allow_big_lds(k_query_sdf<true, false>, LEAN_LDS_BYTES)) return e;

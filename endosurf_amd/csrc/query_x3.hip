@@ -239,14 +239,7 @@ int pack_x3r(const float* weff, void* packed, int use_deform, hipStream_t st);
 int query_sdf_x3r(const PointSrc& src, const void* packed, const float* weff, float* sdf_out, int use_deform, hipStream_t st, int ld_out,
                   const int* ray_done);
 constexpr int X3_SMALL_MAX = 8192;      // batches up to here run the 32-point LDS-resident tiles
-static bool use_x3r() {
-#ifdef ES_DEV_SWITCHES      // dev builds only: ES_X3R=0 selects the LDS-resident kernel of this file (A/B measurements)
-    static const bool v = [] { const char* e = getenv("ES_X3R"); return !(e && e[0] == '0'); }();
-    return v;
-#else
-    return true;
-#endif
-}
+static bool use_x3r() { return true; }      // (large batches: the register-resident kernel of query_x3r.hip; round 3's A/B switch is gone)
 size_t packed_x3_bytes() { return X3_UNITS * 16 + packed_x3r_bytes(); }
 const void* packed_x3r_part(const void* packed_x3) { return static_cast<const unsigned char*>(packed_x3) + X3_UNITS * 16; }
 

@@ -3,32 +3,48 @@
 #include <vector>
 
 #include "../../include/endosurf_hip.h"
+#include "device_table.h"
 #include "launch.h"
 
 namespace es {
 
+// One timer state per DEVICE (the launches of a device come from one host thread: include/endosurf_hip.h): switch, recorded launches and
+// the pool of events (events belong to the device they were created on).  Two engines on two GPUs of one process time independently.
 struct TimedLaunch { int kid; long long rows; hipEvent_t a, b; };
-static bool g_timing_on = false;
-static std::vector<TimedLaunch> g_launches;
-static std::vector<hipEvent_t> g_pool;
+struct TimingState {
+    bool on = false;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> pool;
+};
+static DeviceTable<TimingState> g_timing;
+static int g_any_on = 0;          // number of devices with timers on: the launch path of an untimed process skips the device query
 
-static hipEvent_t get_event() {
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+static TimingState& cur_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return g_timing.at(dev);
+}
+static hipEvent_t get_event(TimingState& s) {
+    if (!s.pool.empty()) { hipEvent_t e = s.pool.back(); s.pool.pop_back(); return e; }
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
 void timing_begin(int kid, long long rows, hipStream_t st) {
-    if (!g_timing_on) return;
-    TimedLaunch t{kid, rows, get_event(), get_event()};
+    if (!g_any_on) return;
+    TimingState& s = cur_state();
+    if (!s.on) return;
+    TimedLaunch t{kid, rows, get_event(s), get_event(s)};
     if (!t.a || !t.b) return;
     hipEventRecord(t.a, st);
-    g_launches.push_back(t);
+    s.launches.push_back(t);
 }
 void timing_end(int kid, hipStream_t st) {
-    if (!g_timing_on || g_launches.empty()) return;
-    TimedLaunch& t = g_launches.back();
+    if (!g_any_on) return;
+    TimingState& s = cur_state();
+    if (!s.on || s.launches.empty()) return;
+    TimedLaunch& t = s.launches.back();
     if (t.kid == kid) hipEventRecord(t.b, st);
 }
 
@@ -38,14 +54,21 @@ using namespace es;
 
 extern "C" {
 
+// the CURRENT device's timers (callers run under hipSetDevice / torch.cuda.device of their engine)
 int es_timing_enable(int on) {
-    g_timing_on = on != 0;
+    TimingState& s = cur_state();
+    const bool want = on != 0;
+    if (want != s.on) g_any_on += want ? 1 : -1;
+    s.on = want;
     return ST_OK;
 }
 
-// Drains the recorded launches (synchronising on their events): for i < min(n, capacity): kid[i], rows[i], ms[i].
+// Drains the launches recorded on the current device (synchronising on their events): for i < min(n, capacity): kid[i], rows[i], ms[i].
 int es_timing_drain(int capacity, int* kid, long long* rows, float* ms, int* n_out) {
     int n = 0;
+    TimingState& s = cur_state();
+    auto& g_launches = s.launches;
+    auto& g_pool = s.pool;
     for (auto& t : g_launches) {
         float v = 0.f;
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&v, t.a, t.b) == hipSuccess && n < capacity) {

@@ -22,7 +22,7 @@
 
 namespace es {
 
-#ifdef ES_PROFILE_WGRAD       // dev builds only: cycle stamps of block 0 / thread 0 inside the fp32 task (tools/wgrad_profile.py)
+#ifdef ES_PROFILE_WGRAD       // dev builds only: cycle stamps of block 0 / thread 0 inside the fp32 task (tools/dev/wgrad_profile.py)
 __device__ long long w_prof[128];
 #define W_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) w_prof[i] = __builtin_readcyclecounter(); } while (0)
 extern "C" int es_debug_w_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w_prof), sizeof(long long) * (n < 128 ? n : 128)); }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_wgrad(WgArgs a) {
 //     pinned with sched_barrier; the stage body is branch-free (rows past the chunk's end are staged as zeros through selects).
 // Problems with few input features (first layers, skip columns: K = 39 / 52 / 93) take the same path (their missing columns are
 // whatever the clamped loads return; those output columns are never stored).
-// Measured (tools/wgrad_x3_probe.py: one [1.65 M x 256] x [1.65 M x 256] problem = the deformation launch's rows; tools/pmc_probe.sh;
+// Measured (tools/dev/wgrad_x3_probe.py: one [1.65 M x 256] x [1.65 M x 256] problem = the deformation launch's rows; tools/dev/pmc_probe.sh;
 // -DES_WX_NO_MFMA / -DES_WX_NO_SPLIT builds): gaussian operands 1.31 ms at 1.56 GHz (MFMA busy 0.61); MFMAs + fragment reads alone
 // 0.78 ms at 1.80 GHz (busy 0.895); loads + split + panel writes alone 0.60 ms at 1.99 GHz (5.7 TB/s); all-zero operands 0.92 / 0.62 /
 // 0.53 ms -- the clock follows the power drawn, and the parts ADD: a stage costs 3 465 cycles of MFMA stream + ~1 585 for its 257 VALU and

@@ -102,10 +102,6 @@ inline WsLayout ws_layout(int M, int flags) {
 
 // a colour-less tail [m_color, M) behind a tile-aligned main part (the fused training batch): see point_fwd.hip
 inline bool aux_tail(int flags, int m_color, int M) {
-#ifdef ES_DEV_SWITCHES      // dev builds only: ES_NO_TAIL_MIX=1 runs the tail as launches of its own (A/B measurements)
-    static const bool off = getenv("ES_NO_TAIL_MIX") != nullptr;
-    if (off) return false;
-#endif
     return (flags & PF_COLOR) && m_color > 0 && m_color < M && m_color % 64 == 0;
 }
 

@@ -34,7 +34,7 @@ __device__ __forceinline__ float softplus100_native(float z) {
 #ifndef X3_PTS
 #define X3_PTS 64
 #endif
-// Cycle stamps (-DX3_PROFILE, tools/x3_profile.py) of one 256-wide softplus layer, 8 waves: GEMM 14.5 k cycles for wave 0 + 3.9 k waiting
+// Cycle stamps (-DX3_PROFILE, tools/dev/x3_profile.py) of one 256-wide softplus layer, 8 waves: GEMM 14.5 k cycles for wave 0 + 3.9 k waiting
 // at the barrier for its SIMD partner (12.3 k of MFMA issue for the pair: the GEMM phase is ~66 % efficient), epilogue 4.7 k + 2.4 k
 // waiting for the partner's: 25.6 k per layer, 48 % of it MFMA.  16 waves: the GEMM phase grows to 22.5 k (twice the weight-fragment
 // requests: L1 delivers 64 B/clk hit or miss) -> 2.15 ms instead of 1.89 ms per training step; 4 waves: 26.6 k (one wave per SIMD cannot

@@ -98,7 +98,7 @@ struct WStream {
     }
 };
 
-#ifdef XR_PROFILE        // dev builds only (tools/xr_profile.sh): cycle stamps of block 0 / wave 0
+#ifdef XR_PROFILE        // dev builds only (tools/dev/xr_profile.sh): cycle stamps of block 0 / wave 0
 extern __device__ long long xr_prof[512];
 #define XR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) xr_prof[i] = __builtin_readcyclecounter(); } while (0)
 #define XR_ADD(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) xr_prof[i] += (v); } while (0)

@@ -285,3 +285,39 @@ def test_pmc_figures_are_per_single_launch_and_plausible():
     gbps, ghz, note = bench.pmc_rates(pm, 1.283)
     assert note is None and 1.0 <= ghz <= 2.6 and gbps < 100
     assert bench.pmc_rates(pm, 0.6)[2] is not None and bench.pmc_rates(pm, 0.6)[:2] == (None, None)       # 4.7 GHz: withheld
+
+
+def test_device_table_slots_are_independent(tmp_path):
+    """csrc/device_table.h (the per-device state of the opt-in kernel timers, csrc/timing.hip): every device ordinal has its own slot,
+    out-of-range ordinals stay in bounds.  Plain C++: compiled with g++ and run here."""
+    import os
+    import shutil
+    import subprocess
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('''
+#include <vector>
+#include <cstdio>
+#include "device_table.h"
+struct S { bool on = false; std::vector<int> rec; };
+int main() {
+    static es::DeviceTable<S> t;
+    t.at(0).on = true; t.at(0).rec.push_back(7);
+    t.at(3).rec.push_back(9); t.at(3).rec.push_back(10);
+    if (t.at(1).on || !t.at(1).rec.empty()) return 1;           // untouched device: default state
+    if (!t.at(0).on || t.at(0).rec.size() != 1 || t.at(3).on || t.at(3).rec.size() != 2) return 2;
+    t.at(0).rec.clear();                                          // draining device 0 leaves device 3 alone
+    if (t.at(3).rec.size() != 2) return 3;
+    if (&t.at(-5) != &t.at(0) || &t.at(1000) != &t.at(63)) return 4;   // out-of-range ordinals: clamped, never out of bounds
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    inc = os.path.join(REPO, "endosurf_amd", "csrc")
+    subprocess.run([gxx, "-std=c++17", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev tool: A/B two builds of the library on the same GPU box.  usage: bash tools/ab.sh [rounds] [extra bench flags]
+# Dev tool: A/B two builds of the library on the same GPU box.  usage: bash tools/dev/ab.sh [rounds] [extra bench flags]
 # expects endosurf_amd/lib/variant_A.so and variant_B.so; alternates them and prints ms per step of bench.py
 L=endosurf_amd/lib
 R=${1:-3}; shift

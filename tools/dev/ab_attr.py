@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): A/B an Engine attribute inside ONE process: alternating blocks of training steps with the attribute off / on.
-usage: python tools/ab_attr.py <attribute> [rounds]"""
+usage: python tools/dev/ab_attr.py <attribute> [rounds]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench as B
 from endosurf_amd import EndoSurfRenderer

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev tool: A/B two builds of the library in split-precision mode on the same GPU box.  usage: bash tools/ab_split.sh [rounds]
+# Dev tool: A/B two builds of the library in split-precision mode on the same GPU box.  usage: bash tools/dev/ab_split.sh [rounds]
 L=endosurf_amd/lib
 for r in $(seq ${1:-2}); do
   for v in ${VARIANTS:-A B}; do

@@ -3,7 +3,7 @@
 schedules: S1 = as shipped (sampling chain starts on the side stream AFTER the marching query), S2 = the sampling chain starts together with
 the marching query.  Prints ms per front end."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench as B
 from endosurf_amd import EndoSurfRenderer

@@ -1,5 +1,5 @@
 """Dev tool: host time to ISSUE a training step (no synchronisation) against its wall time: 3.4 ms of 13.4 / 11.8 ms (fp32 / split-precision,
-marching early exit on): the step is GPU-bound with a 3-4x margin on the host.  usage: [ES_SPLIT_BF16=1] python tools/issue_time.py"""
+marching early exit on): the step is GPU-bound with a 3-4x margin on the host.  usage: [ES_SPLIT_BF16=1] python tools/dev/issue_time.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench as B

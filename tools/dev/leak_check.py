@@ -1,6 +1,6 @@
 """Dev tool: GPU memory must be flat over many training steps (reference cycles through autograd nodes would leak ~7 GB/step)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench as B
 from endosurf_amd import EndoSurfRenderer

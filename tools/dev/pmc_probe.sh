@@ -1,6 +1,6 @@
 #!/bin/bash
-# Dev tool: SQ counters of the bare split-precision weight-gradient GEMM (tools/wgrad_x3_probe.py) for library variants.
-# usage: VARIANTS="B C E" bash tools/pmc_probe.sh   -> gpurun_out/pmc_probe.txt
+# Dev tool: SQ counters of the bare split-precision weight-gradient GEMM (tools/dev/wgrad_x3_probe.py) for library variants.
+# usage: VARIANTS="B C E" bash tools/dev/pmc_probe.sh   -> gpurun_out/pmc_probe.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}; L=$R/endosurf_amd/lib; export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
 for v in ${VARIANTS:-B}; do
@@ -8,7 +8,7 @@ for v in ${VARIANTS:-B}; do
   for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
               "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
               "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-    rm -rf /tmp/pp; rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pp -o p -- python $R/tools/wgrad_x3_probe.py > /dev/null 2>&1
+    rm -rf /tmp/pp; rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pp -o p -- python $R/tools/dev/wgrad_x3_probe.py > /dev/null 2>&1
     python - "$v" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob('/tmp/pp/**/*counter_collection.csv', recursive=True)

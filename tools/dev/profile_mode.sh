@@ -1,7 +1,7 @@
 #!/bin/bash
-# PMC summary of any bench.py mode on the GPU box:  bash tools/profile_mode.sh <tag> <bench.py arguments ...>
+# PMC summary of any bench.py mode on the GPU box:  bash tools/dev/profile_mode.sh <tag> <bench.py arguments ...>
 #   profiles/<tag>_pmc_summary.json   three separate --pmc passes (SQ counters | FETCH_SIZE | WRITE_SIZE), tools/pmc_summary.py
-# e.g.  bash tools/profile_mode.sh r02e_forward_split --mode forward --split-precision
+# e.g.  bash tools/dev/profile_mode.sh r02e_forward_split --mode forward --split-precision
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 G = os.path.join(REPO, "tests", "golden")
 O = os.path.join(REPO, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
 ref = np.load(os.path.join(G, "psnr_reference_long.npz"))["curve"]

@@ -2,7 +2,7 @@
 """Dev tool (library built with -DES_DEV_SWITCHES): the SDF query kernel under the variant ES_QT selects -- outputs of a few batch
 shapes dumped for a bit-wise comparison between variants, and the launch time of the two sizes a training step runs.
 
-    ES_QT=0 python tools/qt_ab.py a; ES_QT=1 python tools/qt_ab.py b; python tools/qt_ab.py cmp a b"""
+    ES_QT=0 python tools/dev/qt_ab.py a; ES_QT=1 python tools/dev/qt_ab.py b; python tools/dev/qt_ab.py cmp a b"""
 import json
 import os
 import sys

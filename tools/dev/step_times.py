@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): host time vs total time of a training step (is the Python orchestration ever the bottleneck?).
-usage: python tools/step_times.py [config 2|3|4]"""
+usage: python tools/dev/step_times.py [config 2|3|4]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import bench as B

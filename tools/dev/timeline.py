@@ -1,5 +1,5 @@
 """Dev tool: condense a rocprofv3 --kernel-trace csv into a per-step timeline (large kernels, runs of tiny ones, idle gaps).
-usage: python tools/timeline.py <kernel_trace.csv> [step_index_from_end]"""
+usage: python tools/dev/timeline.py <kernel_trace.csv> [step_index_from_end]"""
 import csv, sys
 rows = []
 with open(sys.argv[1]) as f:

@@ -1,5 +1,5 @@
 """Dev tool: time the bare split-precision weight-gradient GEMM (es_gemm_atb) on a problem of the training step's size: 256 tasks of
-~6 400 rows.  usage: python tools/wgrad_x3_probe.py [rows]   (prints ms, TB/s of operand bytes, bf16 TFLOP/s incl. the six products)"""
+~6 400 rows.  usage: python tools/dev/wgrad_x3_probe.py [rows]   (prints ms, TB/s of operand bytes, bf16 TFLOP/s incl. the six products)"""
 import sys
 import torch
 from endosurf_amd import _lib

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev tool: build instrumented / ablated variants of csrc/query_x3r.hip (here, no GPU needed), then `bash tools/xr_profile.sh run` on the GPU box.
+# Dev tool: build instrumented / ablated variants of csrc/query_x3r.hip (here, no GPU needed), then `bash tools/dev/xr_profile.sh run` on the GPU box.
 cd "$(dirname "$0")/.."
 L=endosurf_amd/lib; B=endosurf_amd/build; S=endosurf_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
@@ -17,6 +17,6 @@ fi
 cp $L/libendosurf_hip.so /tmp/orig.so
 for name in ${VARIANTS:-prof1 prof2 novalu nodma nobar nodmabar nothing}; do
   cp $L/xr_$name.so $L/libendosurf_hip.so
-  echo "== $name"; python tools/xr_profile.py
+  echo "== $name"; python tools/dev/xr_profile.py
 done
 cp /tmp/orig.so $L/libendosurf_hip.so

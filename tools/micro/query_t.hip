@@ -21,8 +21,9 @@
 // its own 64 entries).  LDS: 64 x 260 + 64 x 60 floats = exactly 80 KiB, two workgroups per CU as before.
 // STATUS (round 5): measured and NOT kept.  Bit-identical to query.hip on every shape tried, and the same speed to +-0.3 % (1.893 vs 1.891 ms
 // on the 131 072-point launch): the LDS instruction count is not what bounds these kernels (DEAD_ENDS.md, profiles/r05_ab_query_transposed.txt).
-// This translation unit is compiled only into dev builds (python -m endosurf_amd.build -DES_DEV_SWITCHES), where ES_QT selects it and
-// its timing-experiment instantiations (tools/qt_ab.py); the product library does not contain it.
+// Round 6: moved out of endosurf_amd/csrc (the product sources hold only what ships).  To measure it again: copy this file back into
+// endosurf_amd/csrc, declare query_sdf_t in query.hip and route query_sdf() to it (the round-5 hook read ES_QT: 1 = both tile heights,
+// 2 = 64-point tiles only, >= 100: the timing-experiment instantiations tools/dev/qt_ab.py drives), build with -DES_DEV_SWITCHES.
 #ifdef ES_DEV_SWITCHES
 #include <cstdlib>
 
