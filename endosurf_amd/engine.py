@@ -491,6 +491,8 @@ def _point_backward(self, ctx: PointCtx, weff, packed, d_sdf, d_go, d_rgb=None, 
         assert d_rgb.shape[0] == mc
     if dweff is None:
         dweff = self.zeros(self.n_weff)
+        if self._grad_pipeline is not None:          # a pipelined data-parallel step counts the gradient buffers of its weff consumers
+            self._grad_pipeline["buffers"] = self._grad_pipeline.get("buffers", 0) + 1
     if ctx.x3_chain:      # the workspace of the split-precision training chain: that family's backward kernels
         check(self.lib.es_point_backward_x3(C.byref(ctx.pts), ptr(packed), ptr(ctx.px3), ptr(weff), ptr(ctx.ws), ctx.flags, ctx.m_color, ptr(d_sdf),
                                             ptr(d_go), ptr(d_rgb) if color else None, ptr(dweff), ptr(self.wg_scratch()), self.st()),

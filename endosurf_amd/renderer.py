@@ -444,7 +444,7 @@ class _PackFn(torch.autograd.Function):
         if dweff is None:
             return (None, None, *[None for _ in ctx.slots])
         pipe = getattr(ctx.eng, "_grad_pipeline", None)
-        if pipe is not None and pipe.get("dflat") is not None and pipe.get("dweff_ptr") == (dweff.data_ptr(), dweff._version):
+        if pipe is not None and pipe.get("dflat") is not None and pipe.get("dweff_ptr") == dweff.data_ptr() and pipe.get("buffers") == 1:
             pipe["adopted"] = True
             # a pipelined data-parallel step (trainer.Trainer overlap_allreduce): the hooks behind the weight-gradient launches have
             # already written (and are all-reducing) the finished layers' slices; the rest -- whatever the hooks left -- is done here
@@ -838,7 +838,7 @@ class EndoSurfRenderer(nn.Module):
         key = ((tuple(p._version for p in plist), m._epoch), want_grad)
         c = m._pack_cache
         if c is not None and c[0] == key:
-            m._check_views(spot=True)
+            m._check_views()          # (the full walk over the cached slots: ~6 us)
             if m._pack_cache is c:          # (a re-bound parameter was folded back: _rebind dropped the cache)
                 return c[1], c[2]
         m._check_views()

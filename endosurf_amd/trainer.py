@@ -583,9 +583,10 @@ class Trainer:
         pipe = eng._grad_pipeline
         plan = self._bucket_plan()
         if pipe["dflat"] is None:
-            # the tag _PackFn.backward recognises the hooks' buffer by: the tensor's address AND its version counter (autograd sums the
-            # gradients of several consumers of weff, possibly in place into the first one: same address, other contents)
-            pipe["dflat"], pipe["dweff_ptr"], pipe["remaining"] = eng.zeros(eng.n_param), (dweff.data_ptr(), dweff._version), plan["remaining"]
+            # _PackFn.backward recognises the hooks' buffer by its address AND by the step having produced exactly ONE gradient buffer
+            # of the effective weights (autograd sums the gradients of several consumers, possibly in place into the first one: same
+            # address, other contents; Engine.point_backward counts the buffers in pipe["buffers"])
+            pipe["dflat"], pipe["dweff_ptr"], pipe["remaining"] = eng.zeros(eng.n_param), dweff.data_ptr(), plan["remaining"]
         job = plan["A"] if stage == _lib.BWD_WGRAD_DEFORM else (plan["B"] if stage == _lib.BWD_WGRAD_SDF else None)
         if job is None:
             return
