@@ -623,7 +623,7 @@ class ReferenceLoop:
 
     W = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)      # base_pull.yml:23-29
 
-    def __init__(self, ctx, logging=False, config_id=2):
+    def __init__(self, ctx, logging=False, config_id=2, flat_adam=False):
         import torch
         from endosurf_amd import EndoSurfRenderer
         from endosurf_amd.trainer import SyntheticScene
@@ -636,6 +636,9 @@ class ReferenceLoop:
         for key in train_params.keys():
             grad_vars += train_params[key]
         self.optimizer = torch.optim.Adam(params=grad_vars, lr=5e-4)
+        if flat_adam:          # the ONE further line INTEGRATION.md offers a maintainer: the same update as one launch over the flat buffer
+            from endosurf_amd.trainer import FlatAdam
+            self.optimizer = FlatAdam(self.renderer, lr=5e-4)
         self.lr_init, self.n_iter = 5e-4, 100000
         scene = SyntheticScene(ctx.dev, seed=1234 + ctx.rank)
         self.batches = [scene.batch(cfg["rays"]) for _ in range(4)]
@@ -741,9 +744,10 @@ class ReferenceLoop:
                     host_issue_ms=issue, host_syncs_per_step=syncs, library_calls_per_step=calls,
                     sum_timed_kernel_ms=sum(per.values()) if per else None, kernel_ms_per_step=per or None,
                     aux_rows_in_render_workspace=(tail.cap if tail is not None else 0),
-                    optimizer="torch.optim.Adam(params=grad_vars, lr) over %d tensors, torch defaults (%s)" % (
-                        len(opt.param_groups[0]["params"]),
-                        "foreach" if opt.param_groups[0].get("foreach") in (None, True) and not opt.param_groups[0].get("fused") else "fused"))
+                    optimizer=("endosurf_amd.trainer.FlatAdam(renderer, lr): the same update as one launch" if "params" not in opt.param_groups[0] else
+                               "torch.optim.Adam(params=grad_vars, lr) over %d tensors, torch defaults (%s)" % (
+                                   len(opt.param_groups[0]["params"]),
+                                   "foreach" if opt.param_groups[0].get("foreach") in (None, True) and not opt.param_groups[0].get("fused") else "fused")))
 
 
 def reference_call_sequence(ctx, args, steps=None):
@@ -754,8 +758,8 @@ def reference_call_sequence(ctx, args, steps=None):
     short = args.steps < 10
     steps = steps or (4 if short else 20)
     out = {}
-    for name, logging in (("plain", False), ("with_reference_logging", True)):
-        loop = ReferenceLoop(ctx, logging=logging)
+    for name, logging, flat in (("plain", False, False), ("with_reference_logging", True, False), ("plain_with_flat_adam", False, True)):
+        loop = ReferenceLoop(ctx, logging=logging, flat_adam=flat)
         out[name] = loop.measure(3, steps, timing_steps=2 if short else 3)
         loop = None
         gc.collect()
@@ -764,7 +768,8 @@ def reference_call_sequence(ctx, args, steps=None):
                    "src.renderer.endosurf.EndoSurfRenderer replaced by endosurf_amd.EndoSurfRenderer and nothing else: renderer(rays) -> "
                    "errorondepth -> surface_neighbour_error as three calls, torch loss arithmetic, loss.backward(), torch.optim.Adam.step() "
                    "over the parameter tensors, loss.item(); 'with_reference_logging' adds cal_psnr's three D2H copies and the ten "
-                   "add_scalar(tensor) host syncs of :165-179.  ms_per_step is wall time per iteration (every iteration ends in a host "
+                   "add_scalar(tensor) host syncs of :165-179; 'plain_with_flat_adam' replaces the optimiser line by endosurf_amd.trainer.FlatAdam (the one "
+                   "further change INTEGRATION.md offers).  ms_per_step is wall time per iteration (every iteration ends in a host "
                    "sync, so host issue and GPU work of consecutive steps do not overlap)")
     return out
 
@@ -899,7 +904,7 @@ def main():
     ap.add_argument("--rays", type=int, default=None, help="override the configuration's rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default=None, choices=["train", "forward", "frame"])
-    ap.add_argument("--refseq-only", choices=["plain", "logging"], default=None,
+    ap.add_argument("--refseq-only", choices=["plain", "logging", "flat_adam"], default=None,
                     help="profiling aid: run ONLY the reference trainer's own loop through the drop-in (ReferenceLoop) and print its record")
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
@@ -959,7 +964,7 @@ def main():
                 else dict(pinned=False, reason="one rank" if world == 1 else "--no-pin"))
 
     if args.refseq_only:
-        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging")
+        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging", flat_adam=args.refseq_only == "flat_adam")
         print(json.dumps(loop.measure(args.warmup, args.steps)), flush=True)
         return
 

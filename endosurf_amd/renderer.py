@@ -843,6 +843,8 @@ class EndoSurfRenderer(nn.Module):
                 return c[1], c[2]
         m._check_views()
         key = ((tuple(p._version for p in plist), m._epoch), want_grad)          # (after the walk: folding a parameter back bumps the epoch)
+        if c is not None and c[0][0] != key[0]:
+            self._live_tail = None          # new weights: the last render's tail (and, if it was never back-propagated, its workspace) can go
         c = m._pack_cache
         plist = list(plist)
         if c is not None and not want_grad and c[0] == (key[0], True):

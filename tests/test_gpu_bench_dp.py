@@ -116,7 +116,7 @@ def test_bench_default_line_carries_extras():
     # on the two auxiliary calls' points live in the render's workspace (3 x 1024 rows)
     rs = ex.pop("reference_call_sequence")
     assert "error" not in rs, rs
-    for k in ("plain", "with_reference_logging"):
+    for k in ("plain", "with_reference_logging", "plain_with_flat_adam"):
         e = rs[k]
         assert e["ms_per_step"] > 0 and e["value"] > 0 and e["sum_timed_kernel_ms"] > 0 and e["aux_rows_in_render_workspace"] == 3072, (k, e)
         assert e["with_early_exit"]["ms_per_step"] > 0
