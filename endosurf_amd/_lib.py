@@ -125,7 +125,7 @@ QUERY_TILE_RACING = 32      # include/endosurf_hip.h ES_QUERY_TILE_RACING
 PF_DEFORM, PF_COLOR, PF_SAVE, PF_X3 = 1, 2, 4, 8
 WS_XC, WS_V, WS_SDF, WS_FEAT, WS_GC, WS_GO, WS_RGB = range(7)
 BWD_CHAINS, BWD_WGRAD_DEFORM, BWD_WGRAD_SDF, BWD_WGRAD_COLOR = 1, 2, 4, 8          # es_point_backward_stages
-WS_XCBAR, WS_CURV = 27, 34          # (include/endosurf_hip.h ES_WS_XCBAR / ES_WS_CURV)
+WS_XCBAR, WS_CURV, WS_TBAR, WS_VBAR = 27, 34, 35, 23          # (include/endosurf_hip.h ES_WS_XCBAR / ES_WS_CURV / ES_WS_TBAR / ES_WS_VBAR)
 
 _lib = None
 

@@ -203,17 +203,17 @@ __device__ __forceinline__ void color_bwd_tile(const BwdArgs& a, const int tile)
         float* Vb = wsb(a, WS_VBAR_C) + gp * 3;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { xb[j] = tx[j * 64 + tid]; gb[j] = SB[gp * 128 + 63 + j]; }
-        if (deform) {   // d_c = v/(|v| + eps), v = J d  ->  vbar (seeds the J d row of the deformation backward)
+        {   // d_c = v/(|v| + eps), v = J d (the view direction itself without a deformation network)  ->  vbar: seeds the J d row of the
+            // deformation backward; public as ES_WS_VBAR (the adjoint of the view direction, up to J^T: EndoSurfNet.forward's input gradient)
             const float* vv = wsb(a, WS_V) + gp * 3;
-            const float v[3] = {vv[0], vv[1], vv[2]}, db[3] = {td[tid], td[64 + tid], td[128 + tid]};
+            const float v[3] = {deform ? vv[0] : dray[0], deform ? vv[1] : dray[1], deform ? vv[2] : dray[2]};
+            const float db[3] = {td[tid], td[64 + tid], td[128 + tid]};
             const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
             const float den = n + 1e-10f;
             const float dot = v[0] * db[0] + v[1] * db[1] + v[2] * db[2];
             const float k2 = n > 0.f ? dot / (n * den * den) : 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) Vb[i] = db[i] / den - v[i] * k2;
-        } else {
-            Vb[0] = Vb[1] = Vb[2] = 0.f;
         }
     }
 }

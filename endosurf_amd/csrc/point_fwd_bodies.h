@@ -270,6 +270,19 @@ __device__ __forceinline__ void deform_vjp_tile(const FwdArgs& a, const int tile
             wsb(a, WS_GO)[(grow0 + row) * 3 + j] = g;
             wsb(a, WS_CURV)[(grow0 + row) * 3 + j] = c2;
         }
+    } else {   // the adjoint of the TIME input under the same covector: <g_c, d x_c / d t> (raw t + its six sin / cos pairs: rows 39..51)
+        const int row = tid & 63;
+        float x[3], t, d[3];
+        load_point(a.src, row0 + row, x, t, d);
+        float g = aux[swz(39, row)];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float f = (float)(1 << i);
+            float s, co;
+            sincosf(t * f, &s, &co);
+            g += f * (aux[swz(39 + enc_index(1, i, 0, 0), row)] * co - aux[swz(39 + enc_index(1, i, 1, 0), row)] * s);
+        }
+        if (!HALF || (row >> 5) == RT0) wsb(a, WS_TBAR)[grow0 + row] = g;
     }
 }
 

@@ -14,9 +14,11 @@
 namespace es {
 
 #ifdef ES_PROFILE_QUERY      // dev builds only: cycle stamps of block 0 / thread 0 at the phase boundaries (tools/dev/q_profile.py)
-__device__ long long q_prof[64];
-#define Q_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) q_prof[i] = __builtin_readcyclecounter(); } while (0)
-extern "C" int es_debug_q_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_prof), sizeof(long long) * (n < 64 ? n : 64)); }
+__device__ long long q_prof[192];      // [0, 64): block 0 (first round) | [64, 128): the last block (last round) | [128, 192): their wall clocks (100 MHz)
+#define Q_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+        const int b_ = blockIdx.x == 0 ? 0 : 64; q_prof[b_ + (i)] = __builtin_readcyclecounter(); \
+        if ((i) == 0 || (i) == 7) q_prof[128 + (b_ >> 1) + (i)] = wall_clock64(); } } while (0)
+extern "C" int es_debug_q_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_prof), sizeof(long long) * (n < 192 ? n : 192)); }
 #else
 #define Q_STAMP(i) do {} while (0)
 #endif

@@ -57,9 +57,11 @@ enum WsBuf : int {
     WS_CURV,       // [Mp][3]  c_j = sum_i 4^i (ebar_sin(i,j) sin(2^i x_j) + ebar_cos(i,j) cos(2^i x_j)), ebar = the adjoint of the deformation
                    //          network's encoding input for the covector in WS_GC: minus the diagonal of sum_k g_c[k] d2 x_c[k] / dx^2 (the
                    //          encodings act per coordinate).  Written by the VJP sweep; the second-order term of d g_o / d x (es_point_vjp)
+    WS_TBAR,       // [Mp]     the VJP sweep's adjoint of the TIME input: <c, d x_c / d t> for the covector c in WS_GC (public id ES_WS_TBAR)
     WS_COUNT
 };
-static_assert(WS_XCBAR == 27 && WS_CURV == 34, "public buffer ids of include/endosurf_hip.h (ES_WS_XCBAR, ES_WS_CURV)");
+static_assert(WS_XCBAR == 27 && WS_CURV == 34 && WS_TBAR == 35 && WS_VBAR_C == 23,
+              "public buffer ids of include/endosurf_hip.h (ES_WS_XCBAR, ES_WS_CURV, ES_WS_TBAR, ES_WS_VBAR)");
 
 struct WsLayout {
     size_t off[WS_COUNT + 1];
@@ -78,6 +80,7 @@ inline WsLayout ws_layout(int M, int flags) {
     sz[WS_XC] = Mp * 3; sz[WS_V] = Mp * 3; sz[WS_SDF] = Mp; sz[WS_GC] = Mp * 3; sz[WS_GO] = Mp * 3;
     sz[WS_D_MASK] = def ? 8 * (Mp / 32) * 256 : 0;
     sz[WS_CURV] = def ? Mp * 3 : 0;
+    sz[WS_TBAR] = def ? Mp : 0;
     sz[WS_FEAT] = col ? Mp * 256 : 0; sz[WS_RGB] = col ? Mp * 3 : 0;
     sz[WS_C_IN] = col ? Mp * 128 : 0;      // always: the colour kernel re-stages it at the skip layer
     sz[WS_S_ACT] = 8 * Mp * 256;

@@ -431,7 +431,8 @@ class Engine:
 class PointCtx:
     """Workspace of one fused point evaluation + typed views of its outputs."""
     _OUT = {"xc": (_lib.WS_XC, 3), "v": (_lib.WS_V, 3), "sdf": (_lib.WS_SDF, 1), "feat": (_lib.WS_FEAT, 256),
-            "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3), "curv": (_lib.WS_CURV, 3), "xcbar": (_lib.WS_XCBAR, 3)}
+            "gc": (_lib.WS_GC, 3), "go": (_lib.WS_GO, 3), "rgb": (_lib.WS_RGB, 3), "curv": (_lib.WS_CURV, 3), "xcbar": (_lib.WS_XCBAR, 3),
+            "tbar": (_lib.WS_TBAR, 1), "vbar": (_lib.WS_VBAR, 3)}
 
     def __init__(self, eng: "Engine", pts, flags: int, m_color: int = 0):
         self.eng, self.pts, self.flags, self.M, self.m_color = eng, pts, flags, pts.M, int(m_color)

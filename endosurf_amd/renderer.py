@@ -311,9 +311,9 @@ class EndoSurfNet(nn.Module):
         self._rebind()
 
     # ---- reference query surface (endosurf.py:570-689), evaluated by the fused HIP kernels -------------------------------------
-    # Differentiable w.r.t. the network PARAMETERS (hand-written backward) when grad mode is on.  W.r.t. the query points: the sdf query to
-    # first order (its derivative IS g_o) and mixed with the parameters; nothing else (the reference's callers never ask for more: its own
-    # uses are under no_grad or go through the renderer) -- a RuntimeWarning says so once when points that require grad arrive.
+    # Differentiable w.r.t. the network PARAMETERS (hand-written backward) when grad mode is on, and w.r.t. the query points / inputs where the
+    # reference's are: the sdf query (its derivative IS g_o), the two gradient queries (second order: es_point_vjp) and forward() (position,
+    # view direction and time: _NetForwardFn).
     def _r(self):
         r = self._renderer() if getattr(self, "_renderer", None) is not None else None
         if r is None:
@@ -365,17 +365,6 @@ class EndoSurfNet(nn.Module):
             x, t = self._xt(x, t)
             return r._point_eval(x, t, x_in=x_in)[1]
 
-    _warned_detached = set()
-
-    @classmethod
-    def _warn_points_detached(cls, x, what):
-        if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled() and what not in cls._warned_detached:
-            cls._warned_detached.add(what)
-            import warnings
-            warnings.warn(f"endosurf_amd: {what}: the query points require grad, but this output is differentiable w.r.t. the network "
-                          "parameters only (no second derivative w.r.t. the points: INTEGRATION.md); the points are treated as constants",
-                          RuntimeWarning, stacklevel=3)
-
     def get_sdf_grad_from_canonical_space(self, x):
         """d sdf / d x_c at canonical points [M,3]  (endosurf.py:603-619): the SDF network alone.  Differentiable w.r.t. the parameters and
         the points (the SDF network's Hessian-vector product comes out of its backward as the adjoint of x_c)."""
@@ -404,14 +393,18 @@ class EndoSurfNet(nn.Module):
             return torch.stack(cols, dim=-1)
 
     def forward(self, inputs):
-        """cat([sdf, rgb]) [M,4] for inputs [x, d, t] [M,7]  (endosurf.py:660-689)."""
+        """cat([sdf, rgb]) [M,4] for inputs [x, d, t] [M,7]  (endosurf.py:660-689).  Differentiable w.r.t. the parameters and -- when
+        ``inputs`` requires grad -- w.r.t. the inputs (position, view direction and time: ``_NetForwardFn``)."""
         r = self._r()
         with torch.cuda.device(r.device):
-            self._warn_points_detached(inputs, "EndoSurfNet.forward")
+            weff, packed = r._weights()
+            if self._wrt_points(inputs) is not None:
+                flags = (_lib.PF_DEFORM if self.use_deform else 0) | _lib.PF_COLOR | _lib.PF_SAVE
+                sdf, rgb = _NetForwardFn.apply(weff, packed, r.engine, inputs, flags)
+                return torch.cat([sdf, rgb], -1).reshape(*inputs.shape[:-1], 4)
             inp = inputs.detach().to(torch.float32).reshape(-1, 7)
             x, t = self._xt(inp[:, :3], inp[:, 6])
             d = inp[:, 3:6].contiguous()
-            weff, packed = r._weights()
             pts = r.engine.points(x=x, t=t, dirs=d)
             sdf, _, rgb = _PointEvalFn.apply(weff, packed, r.engine, pts, r._flags(weff) | _lib.PF_COLOR)
             return torch.cat([sdf, rgb], -1)
@@ -521,6 +514,61 @@ class _PointEvalFn(torch.autograd.Function):
                 xbar = eng.point_input_adjoint(pctx, ctx.weff, ctx.packed, d_sdf, d_go).reshape(ctx.x_shape).to(ctx.x_dtype)
         ctx.pctx = None
         return dweff, None, None, None, None, xbar
+
+
+class _NetForwardFn(torch.autograd.Function):
+    """EndoSurfNet.forward (reference endosurf.py:660-689) as a function of the network parameters AND of its inputs [x, d, t]:
+    (sdf [M,1], rgb [M,3]).  The backward to the effective weights is es_point_backward; the adjoint of the inputs is assembled from what
+    that backward leaves in the workspace -- xcbar, the adjoint of x_c over all paths (colour encodings, geometry features, sdf, and the
+    second-order path through the canonical normal g_c), and vbar, the adjoint of v = J d -- with two more reverse sweeps of the
+    deformation network (es_point_vjp):
+        xbar = J^T xcbar - d * curv(vbar)        (curv: the encodings' second derivative against the sweep's adjoint, ES_WS_CURV; the
+        dbar = J^T vbar                           deformation MLP is piecewise linear in its encodings, so d(J d)/dx is this diagonal
+        tbar = <xcbar, d x_c / d t>               and d(J d)/dt = 0 almost everywhere)
+    Without a deformation network x_c = x, v = d: xbar = xcbar, dbar = vbar, tbar = 0."""
+
+    @staticmethod
+    def forward(ctx, weff, packed, eng: Engine, inputs, flags: int):
+        inp = inputs.detach().to(torch.float32).reshape(-1, 7)
+        x, d, t = inp[:, :3].contiguous(), inp[:, 3:6].contiguous(), inp[:, 6].contiguous()
+        pts = eng.points(x=x, t=t, dirs=d)
+        pctx = eng.point_forward(pts, weff, packed, flags, fp32_only=True)
+        ctx.pctx, ctx.eng, ctx.weff, ctx.packed, ctx.pts, ctx.flags, ctx.d = pctx, eng, weff, packed, pts, flags, d
+        ctx.in_shape, ctx.in_dtype = tuple(inputs.shape), inputs.dtype
+        ctx.set_materialize_grads(False)
+        return pctx.view("sdf").clone(), pctx.view("rgb").clone()
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_rgb):
+        eng, pctx = ctx.eng, ctx.pctx
+        if not (ctx.flags & _lib.PF_SAVE):
+            raise RuntimeError("EndoSurfNet.forward was evaluated without saved activations; cannot backpropagate")
+        if pctx is None:          # a second backward through the node: the kernels consumed the workspace, evaluate again
+            with torch.no_grad():
+                pctx = eng.point_forward(ctx.pts, ctx.weff.detach(), ctx.packed, ctx.flags, fp32_only=True)
+        M = pctx.M
+        dweff = eng.point_backward(pctx, ctx.weff, ctx.packed, d_sdf, None, d_rgb)
+        gin = None
+        if ctx.needs_input_grad[3]:
+            gin = eng.empty(M, 7)
+            xcbar, vbar = pctx.view("xcbar").clone(), pctx.view("vbar").clone()
+            if ctx.flags & _lib.PF_DEFORM:
+                def sweep(c):          # J^T c, the curvature sums and the time adjoint of one reverse sweep of the deformation network
+                    pctx.view("gc").copy_(c)
+                    _lib.check(eng.lib.es_point_vjp(_lib.C.byref(pctx.pts), _lib.ptr(ctx.packed), _lib.ptr(ctx.weff.detach()), _lib.ptr(pctx.ws),
+                                                    pctx.flags, eng.st()), "es_point_vjp")
+                    return pctx.view("go").clone(), pctx.view("curv").clone(), pctx.view("tbar").clone()
+                jx, _, tb = sweep(xcbar)
+                jv, cv, _ = sweep(vbar)
+                gin[:, :3] = jx - ctx.d * cv
+                gin[:, 3:6] = jv
+                gin[:, 6:7] = tb
+            else:
+                gin[:, :3], gin[:, 3:6] = xcbar, vbar
+                gin[:, 6] = 0.0
+            gin = gin.reshape(ctx.in_shape).to(ctx.in_dtype)
+        ctx.pctx = None
+        return dweff, None, None, gin, None
 
 
 class _Tail:

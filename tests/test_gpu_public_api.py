@@ -315,3 +315,59 @@ def test_point_adjoint_keeps_the_callers_shape_and_dtype():
     (a,) = torch.autograd.grad(l2, x2, retain_graph=True)
     (b,) = torch.autograd.grad(l2, x2)
     assert torch.allclose(a, x.grad, rtol=1e-5, atol=1e-7) and torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode,use_deform", [("trained", True), ("init", True), ("trained", False)])
+def test_model_forward_is_differentiable_wrt_its_inputs(mode, use_deform):
+    """EndoSurfNet.forward(cat[x, d, t]) -> [sdf, rgb] (endosurf.py:660-689) is an ordinary autograd function of its inputs in the
+    reference.  HIP: xbar = J^T xcbar - d * curv(vbar), dbar = J^T vbar, tbar = <xcbar, d x_c / d t> from the backward's adjoints of x_c and
+    v = J d and two more reverse sweeps of the deformation network (renderer._NetForwardFn).  Against autograd through the fp64 oracle:
+    1e-4 relative on the input gradient, together with the parameter gradients of the same backward."""
+    import weightgen
+    from oracle import endosurf_oracle as O
+    seed, M = 17, 200
+    r = renderer_for(seed, mode, use_deform)
+    state = weightgen.make_state(seed, mode, use_deform)
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state.items()}
+    net = O.OracleNet(params, use_deform)
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-0.8, 0.8, size=(M, 3))
+    d = rng.normal(size=(M, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d *= rng.uniform(0.5, 2.0, size=(M, 1))            # (forward normalises J d itself: its gradient w.r.t. d is tangential)
+    t = rng.uniform(0.0, 1.0, size=(M, 1))
+    inp_np = np.concatenate([x, d, t], -1).astype(np.float32)
+    w_np = rng.normal(size=(M, 4)).astype(np.float32)
+
+    i64 = torch.from_numpy(inp_np).double().requires_grad_(True)
+    o = net.point_eval(i64[:, :3], i64[:, 3:6], i64[:, 6], with_color=True)
+    out64 = torch.cat([o["sdf"], o["rgb"]], -1)
+    (out64 * torch.from_numpy(w_np).double()).sum().backward()
+
+    for p in r.parameters():
+        p.grad = None
+    i32 = torch.from_numpy(inp_np).cuda().requires_grad_(True)
+    out32 = r.model(i32)
+    assert out32.shape == (M, 4) and out32.requires_grad
+    assert float((out32.detach().double().cpu() - out64.detach()).abs().max()) < 5e-5
+    (out32 * torch.from_numpy(w_np).cuda()).sum().backward()
+    gh, go = i32.grad.double().cpu(), i64.grad
+    for name, sl in (("x", slice(0, 3)), ("d", slice(3, 6)), ("t", slice(6, 7))):
+        ref = go[:, sl]
+        if float(ref.norm()) == 0.0:                   # (no deformation network: the output does not depend on the time)
+            assert float(gh[:, sl].abs().max()) == 0.0, name
+            continue
+        rel = float((gh[:, sl] - ref).norm() / ref.norm())
+        assert rel < 1e-4, (name, rel)
+    named = dict(r.named_parameters())
+    keys = ["sdf_network.net.0.weight_v", "sdf_network.net.7.bias", "color_network.net.0.weight_v", "color_network.net.8.bias"] + (
+        ["deform_network.net.1.weight_v", "deform_network.net.6.bias"] if use_deform else [])
+    for k in keys:
+        a, b = named["model." + k].grad.double().cpu(), params[k].grad
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, k
+    # a second backward through the same node (retain_graph) re-evaluates the consumed workspace
+    i32b = torch.from_numpy(inp_np).cuda().requires_grad_(True)
+    s = (r.model(i32b) * torch.from_numpy(w_np).cuda()).sum()
+    (g1,) = torch.autograd.grad(s, i32b, retain_graph=True)
+    (g2,) = torch.autograd.grad(s, i32b)
+    assert float((g1 - g2).abs().max()) <= 1e-6 * float(g1.abs().max()) and float((g1 - i32.grad).abs().max()) <= 1e-5 * float(g1.abs().max())
