@@ -19,8 +19,12 @@ __device__ long long q_prof[192];      // [0, 64): block 0 (first round) | [64, 
         const int b_ = blockIdx.x == 0 ? 0 : 64; q_prof[b_ + (i)] = __builtin_readcyclecounter(); \
         if ((i) == 0 || (i) == 7) q_prof[128 + (b_ >> 1) + (i)] = wall_clock64(); } } while (0)
 extern "C" int es_debug_q_profile(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_prof), sizeof(long long) * (n < 192 ? n : 192)); }
+__device__ long long q_times[2 * 4096];      // wall clock (100 MHz) at the start and the end of every block of the last launch (<= 4096 blocks)
+#define Q_BLOCK_TIME(e) do { if (threadIdx.x == 0 && blockIdx.x < 4096) q_times[2 * blockIdx.x + (e)] = wall_clock64(); } while (0)
+extern "C" int es_debug_q_times(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q_times), sizeof(long long) * (n < 8192 ? n : 8192)); }
 #else
 #define Q_STAMP(i) do {} while (0)
+#define Q_BLOCK_TIME(e) do {} while (0)
 #endif
 
 // HALF: latency-bound small batches (secant iterations, 8-sample up-sampling queries) use 32-point tiles: the LDS tile keeps
@@ -52,6 +56,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     const QuadOff<RTC> qo = quad_offsets<RTC>(0, 2 * wave, lane);
     auto bias2 = [&](float(&b)[2], const float* __restrict__ bias) { b[0] = bias[64 * wave + (lane & 31)]; b[1] = bias[64 * wave + 32 + (lane & 31)]; };
     Q_STAMP(0);
+    Q_BLOCK_TIME(0);
     if (tid < 64) {
         float x[3], t, d[3];
         load_point(src, tid < PTS ? row0 + tid : src.M, x, t, d);
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_query_sdf(PointSrc src, Tabs tb
     smalln_partial<1>(mainT, weff + tb.woff[NET_S * LAYERS + 8], 256, red, tid);
     __syncthreads();
     Q_STAMP(7);
+    Q_BLOCK_TIME(1);
     if (tid < PTS && row0 + tid < src.M) {
         const int i = row0 + tid;
         const size_t o = ld_out > 0 ? (size_t)(i / src.n_per_ray) * ld_out + (i % src.n_per_ray) : (size_t)i;   // [ray][ld_out] or flat

@@ -34,5 +34,26 @@ out["wall_100MHz"] = dict(first_block_us=(w0e - w0) / 100.0, last_block_us=(w1e 
                           last_block_start_after_first_start_us=(w1 - w0) / 100.0)
 print(json.dumps(out["wall_100MHz"]))
 print("launch ms (events):", ms)
+# every block's start / end (100 MHz wall clock): occupancy of the 512 workgroup slots over the launch
+nb = M // 64
+tb = (C.c_longlong * (2 * nb))()
+r.engine.lib.es_debug_q_times.restype = C.c_int
+r.engine.lib.es_debug_q_times(tb, 2 * nb)
+import numpy as np
+T = np.array(list(tb), dtype=np.int64).reshape(nb, 2).astype(np.float64) / 100.0      # us
+t0, t1 = T[:, 0].min(), T[:, 1].max()
+dur = T[:, 1] - T[:, 0]
+span = t1 - t0
+busy = dur.sum()                               # slot-microseconds of work
+slots = 512
+order = np.argsort(T[:, 0])
+rounds = [dur[order[i * slots:(i + 1) * slots]] for i in range((nb + slots - 1) // slots)]
+first_idle = np.sort(T[:, 1])[-slots]           # when the first slot runs out of tiles (the 512th-last end)
+out["slots"] = dict(span_us=span, busy_slot_us=busy, mean_tile_us=float(dur.mean()), occupancy=busy / (span * slots),
+                    tile_us_by_start_round=[dict(mean=float(x.mean()), min=float(x.min()), max=float(x.max())) for x in rounds],
+                    drain_starts_us=float(first_idle - t0), drain_us=float(t1 - first_idle),
+                    drain_idle_share=float(1.0 - dur.sum() / (span * slots)),
+                    start_spread_first_round_us=float(np.sort(T[:, 0])[slots - 1] - t0))
+print(json.dumps(out["slots"], indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/q_stamp.json", "w"), indent=1)
