@@ -63,8 +63,13 @@ constexpr size_t WG_DET_FLOATS = WG_DET_SMALL_OFF + (size_t)WG_MAX_SMALL * WG_MA
 // task index of a problem <-> (k block, row chunk).  The kblk tasks of one row chunk read the same dA rows: they get block ids 8
 // apart (same XCD under the round-robin block -> XCD dispatch, started back to back) so that the second reader hits that XCD's
 // L2 instead of HBM
+#ifdef ES_WG_NOPAIR      // dev builds only (A/B of DEAD_ENDS C5): the k-block tasks of a row chunk on NEIGHBOURING block ids (different XCDs)
+constexpr bool WG_PAIR = false;
+#else
+constexpr bool WG_PAIR = true;
+#endif
 __host__ __device__ inline void wg_decode(int local, int kblk, int nchunk, int& kb, int& mc) {
-    if (kblk == 2) {
+    if (WG_PAIR && kblk == 2) {
         const int grp = local / 16, j = local % 16;
         const int full = (nchunk / 8) * 8;                 // chunks covered by complete groups of 8
         if (grp * 8 < full) { mc = grp * 8 + (j & 7); kb = j >> 3; }
@@ -72,7 +77,7 @@ __host__ __device__ inline void wg_decode(int local, int kblk, int nchunk, int& 
     } else { kb = local % kblk; mc = local / kblk; }
 }
 __host__ __device__ inline int wg_encode(int kb, int mc, int kblk, int nchunk) {
-    if (kblk == 2) {
+    if (WG_PAIR && kblk == 2) {
         const int full = (nchunk / 8) * 8;
         return mc < full ? (mc / 8) * 16 + (mc & 7) + 8 * kb : 2 * full + (((mc - full) << 1) | kb);
     }
