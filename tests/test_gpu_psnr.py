@@ -141,7 +141,7 @@ def _distribution(n_runs, split, tag):
 
 
 N_HIP_RUNS = 5
-N_SPLIT_RUNS = 4
+N_SPLIT_RUNS = 3
 
 
 @pytest.mark.skipif(not os.path.exists(GOLD), reason="reference PSNR curve not generated (tools/psnr_reference.py)")

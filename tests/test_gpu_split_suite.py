@@ -53,13 +53,16 @@ def test_render_level_suite_in_split_precision(force_chain, tmp_path):
     script = tmp_path / "split_suite.py"
     script.write_text(WRAPPER)
     env = dict(os.environ, ES_SPLIT_BF16="1", ES_REPO=REPO, SPLIT_SUITE_FORCE_CHAIN="1" if force_chain else "0")
-    out = subprocess.run([sys.executable, str(script), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *FILES], env=env, capture_output=True,
+    # (as shipped, the parameter-gradient cases of test_gpu_backward.py are what tests/test_gpu_split_precision.py already runs in this very
+    # state -- split-precision weight-gradient GEMMs under fp32 chains --: the subprocess repeats them only with the chain forced)
+    files = FILES if force_chain else [f for f in FILES if not f.endswith("test_gpu_backward.py")]
+    out = subprocess.run([sys.executable, str(script), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *files], env=env, capture_output=True,
                          text=True, timeout=1200, cwd=REPO)
     tail = out.stdout[-4000:] + out.stderr[-2000:]
     assert out.returncode == 0, tail
     line = [l for l in out.stdout.splitlines() if l.startswith("SPLIT_SUITE")][-1]
     engines, chain = (int(t.split("=")[1]) for t in line.split()[1:])
-    assert engines > 10, line
+    assert engines > (10 if force_chain else 5), line
     if force_chain:
         assert chain > 10, line          # the grad-enabled evaluations of the golden cases really ran the split-precision training chain
     log = os.path.join(REPO, "gpurun_out")
