@@ -588,6 +588,7 @@ class _Tail:
         buf = eng.zeros(8 * cap)                      # one allocation, one fill: points (x | t) and adjoints (g_sdf | g_go)
         self.aux_x, self.aux_t = buf[:3 * cap].view(cap, 3), buf[3 * cap:4 * cap]
         self.g_sdf, self.g_go = buf[4 * cap:5 * cap].view(cap, 1), buf[5 * cap:].view(cap, 3)
+        self.gbuf = buf[4 * cap:]                     # both adjoint buffers: cleared again behind every backward that consumed them
         self.pctx, self.weff, self.flags = None, None, 0
 
     def room(self, m64: int, weff, flags: int) -> bool:
@@ -816,6 +817,8 @@ class _RenderFn(torch.autograd.Function):
         ctx.pctx = None                                           # release the workspace as soon as it has been consumed
         if tail is not None:
             tail.pctx = None
+            # (a later pass through this graph -- retain_graph -- must not find this pass's adjoints where a node deposits none)
+            _lib.check(eng.lib.es_zero(_lib.ptr(tail.gbuf), 4 * tail.gbuf.numel(), eng.st()), "es_zero")
         return dweff, None, dvar, None, None, None, None, None, None, None, None, None, None
 
 

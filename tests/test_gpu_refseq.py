@@ -161,3 +161,35 @@ def test_aux_loss_kernels_match_torch():
     assert float((got[1] - gg.grad).abs().max()) < 2e-6 * float(gg.grad.abs().max())
     none = _SnLossFn.apply(gg.detach(), eng, torch.zeros(N, dtype=torch.bool, device="cuda"))
     assert float(none) == 0.0
+
+
+def test_tail_separate_backward_passes():
+    """The reference's graphs of the three calls are disjoint: ``loss_a.backward()`` then ``loss_b.backward()`` works there without
+    retain_graph.  Here the later calls' nodes hang on the render's node (the token), so a second pass re-enters it: the consumed workspace
+    is evaluated again, the accumulated ``.grad`` equals one backward of the sum, and no adjoint of the first pass leaks into the second."""
+    c = load_case("trained_deform")
+    b, u, un = _batch(c)
+    it = int(c["meta/iter_step"])
+    N = b["rays"].shape[0]
+    need = (N + 63) // 64 * 64 + (2 * N + 63) // 64 * 64
+    res = []
+    for separate in (False, True):
+        r = renderer_for_case(c)
+        r.engine.deterministic = True
+        r.perturb = u is not None
+        for p in r.parameters():
+            p.grad = None
+        r._aux_demand = need
+        ret = r(b["rays"], iter_step=it, u_perturb=u)
+        sdf_loss, angle_loss, _ = r.errorondepth(b["rays"], d_gt=b["depth"], mask=b["mask"], iter_step=it)
+        sn = r.surface_neighbour_error(rays=b["rays"], mask=b["mask"], iter_step=it, neighbour_rad=0.1, u_neigh=un)
+        la = ret["color_map"].abs().sum() + ret["gradient_o_error"]
+        lb = sdf_loss + 0.1 * angle_loss
+        lc = 0.1 * sn
+        if separate:
+            la.backward(); lb.backward(); lc.backward()
+        else:
+            (la + lb + lc).backward()
+        torch.cuda.synchronize()
+        res.append(_grads(r))
+    _close(res[0], res[1])
