@@ -321,3 +321,25 @@ int main() {
     subprocess.run([gxx, "-std=c++17", "-I", inc, str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
+def test_hbm_accounting_against_the_committed_counters():
+    """bench.py's algorithmic HBM bytes per launch (HBM_BYTES_PER_POINT x the points of a launch: what the stream-heavy kernels MUST move)
+    beside the committed rocprofv3 traffic of the same symbols (profiles/*_pmc_summary.json): the chain kernels move at most 10 % more than
+    they must, the weight-gradient GEMMs carry the documented second read of dA (DEAD_ENDS C5) and say so."""
+    import os
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, REPO)
+    import bench
+    rows = {r["kernel"]: r for r in bench.hbm_accounting(65536, 3072)}
+    assert set(rows) == {"k_deform_fwd", "k_sdf_fwd", "k_color_fwd", "k_deform_vjp", "k_color_bwd", "k_deform_tan", "k_sdf_bwd", "k_deform_bwd",
+                         "k_wgrad[deform]", "k_wgrad[sdf]", "k_wgrad[color]"}
+    for k, r in rows.items():
+        assert r["pmc_hbm_bytes_per_launch"] and r["algorithmic_bytes_per_launch"] > 0, k
+        if k.startswith("k_wgrad"):
+            assert 1.0 <= r["ratio"] <= 1.6 and "dA" in r["explanation"], (k, r["ratio"])
+        else:
+            assert 0.98 <= r["ratio"] <= 1.10 and r["explanation"] is None, (k, r["ratio"])
+    # the two-sweep floor of the SDF backward: 7 streams x 8 layers x 1 KiB per point
+    assert bench.HBM_BYTES_PER_POINT["sdf_bwd"] >= 7 * 8 * 1024
