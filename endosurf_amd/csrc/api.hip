@@ -188,6 +188,7 @@ int es_variance_terms(const float* variance, const float* d_invs_acc, float* s_v
     return variance_terms(variance, d_invs_acc, s_val, d_var, (hipStream_t)stream);
 }
 int es_march_progress(const float* sdf, int N, int n, int n_valid, float tau, int* done, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(sdf && done && n >= 2 && n_valid >= 1 && n_valid <= n, "es_march_progress arguments");
     return march_progress(sdf, N, n, n_valid, tau, done, (hipStream_t)stream);
 }
@@ -195,30 +196,36 @@ int es_march_progress(const float* sdf, int N, int n, int n_valid, float tau, in
 
 int es_ray_setup(const float* rays, const float* u, int N, int n, float sample_dist, int lin_mode, float* z, int ldz,
                  float* near_out, float* far_out, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(rays && z && N >= 0 && n >= 1 && ldz >= n, "es_ray_setup arguments");
     return ray_setup(rays, u, N, n, sample_dist, lin_mode, z, ldz, near_out, far_out, (hipStream_t)stream);
 }
 int es_upsample_step(const float* rays, const float* z_in, int ld_in, const float* sdf_in, int ld_sdf, int N, int n, int n_imp,
                      float inv_s, float* z_new, float* z_out, int ld_out, int32_t* src_idx, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(rays && z_in && sdf_in && z_new && z_out && src_idx && ld_in >= n && ld_sdf >= n, "es_upsample_step arguments");
     return upsample_step(rays, z_in, ld_in, sdf_in, ld_sdf, N, n, n_imp, inv_s, z_new, z_out, ld_out, src_idx, (hipStream_t)stream);
 }
 int es_merge_sdf(const float* sdf_in, int ld_in, const float* sdf_new, int n_imp, const int32_t* src_idx, int ld_out, int N, int n,
                  float* sdf_out, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(sdf_in && sdf_new && src_idx && sdf_out && sdf_out != sdf_in, "es_merge_sdf arguments (out must not alias in)");
     return merge_sdf(sdf_in, ld_in, sdf_new, n_imp, src_idx, ld_out, N, n, sdf_out, (hipStream_t)stream);
 }
 int es_mid_z(const float* z, int ldz, int N, int S, float sample_dist, float* mid, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(z && mid && ldz >= S && S >= 1, "es_mid_z arguments");
     return mid_z(z, ldz, N, S, sample_dist, mid, (hipStream_t)stream);
 }
 static inline const CompositeArgs& as_comp(const es_composite_args* a) { return *reinterpret_cast<const CompositeArgs*>(a); }
 int es_composite_forward(const es_composite_args* a, void* stream) {
+    if (a && a->N == 0) return ST_OK;      // an empty ray batch
     ES_REQUIRE(a && a->rays && a->z && a->sdf && a->g_o && a->rgb && a->variance, "es_composite_forward inputs");
     ES_REQUIRE(a->color && a->depth && a->weights && a->cdf && a->weight_max && a->eik_acc && a->wmax_idx, "es_composite_forward outputs");
     return composite(as_comp(a), 0, (hipStream_t)stream);
 }
 int es_composite_backward(const es_composite_args* a, void* stream) {
+    if (a && a->N == 0) return ST_OK;      // an empty ray batch
     ES_REQUIRE(a && a->rays && a->z && a->sdf && a->g_o && a->rgb && a->variance, "es_composite_backward inputs");
     ES_REQUIRE(a->n_aux >= 0, "es_composite_backward: negative n_aux");
     ES_REQUIRE(a->g_color && a->g_depth && a->g_eik && a->eik_den && a->d_sdf && a->d_go && a->d_rgb && a->d_invs_acc,
@@ -226,18 +233,22 @@ int es_composite_backward(const es_composite_args* a, void* stream) {
     return composite(as_comp(a), 1, (hipStream_t)stream);
 }
 int es_march_find(const float* sdf, const float* dprop, int N, int n, float tau, float* state, int32_t* flags, float* d_pred, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(sdf && dprop && state && flags && d_pred && n >= 2, "es_march_find arguments");
     return march_find(sdf, dprop, N, n, tau, state, flags, d_pred, (hipStream_t)stream);
 }
 int es_secant_points(const float* rays, const float* d_pred, int N, float* x, float* t, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(rays && d_pred && x && t, "es_secant_points arguments");
     return secant_points(rays, d_pred, N, x, t, (hipStream_t)stream);
 }
 int es_secant_update(const float* sdf_mid, int N, float tau, float* state, float* d_pred, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(sdf_mid && state && d_pred, "es_secant_update arguments");
     return secant_update(sdf_mid, N, tau, state, d_pred, (hipStream_t)stream);
 }
 int es_march_finish(const float* d_pred, const int32_t* flags, int N, float* d_out, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(d_pred && flags && d_out, "es_march_finish arguments");
     return march_finish(d_pred, flags, N, d_out, (hipStream_t)stream);
 }
@@ -405,6 +416,7 @@ int es_render_finish(const float* eik_acc, const float* aux_sdf_ws, const float*
 
 int es_train_aux_points(const float* rays, const float* depth_gt, const float* mask, const float* d_i, const float* u, float rad, int N,
                         float* x, float* t, unsigned char* valid, void* stream) {
+    if (N == 0) return ST_OK;          // an empty ray batch: nothing to do, whatever the (possibly null) buffers
     ES_REQUIRE(rays && depth_gt && mask && d_i && u && x && t && valid && N >= 0, "es_train_aux_points buffers");
     return train_aux_points(rays, depth_gt, mask, d_i, u, rad, N, x, t, valid, (hipStream_t)stream);
 }
@@ -441,8 +453,8 @@ int64_t es_sample_scratch_floats(int N, int n_samples, int n_importance, int up_
 }
 int es_sample_z(const float* rays, const float* u_perturb, int N, int n_samples, int n_importance, int up_sample_steps, int upsample,
                 const float* packed, const float* weff, int use_deform, float* z_out, float* scratch, void* stream) {
-    ES_REQUIRE(rays && z_out && packed && weff && N >= 0 && n_samples >= 2, "es_sample_z arguments");
     if (N == 0) return ST_OK;
+    ES_REQUIRE(rays && z_out && packed && weff && N >= 0 && n_samples >= 2, "es_sample_z arguments");
     hipStream_t st = (hipStream_t)stream;
     const bool do_up = upsample && n_importance > 0 && up_sample_steps > 0;
     const int S = n_samples + (do_up ? n_importance : 0);
@@ -504,6 +516,7 @@ static CompositeArgs render_composite_args(const es_render_args* a, int flags) {
     return c;
 }
 int es_render_forward(const es_render_args* a, const float* packed, const float* weff, void* stream) {
+    if (a && a->c.N == 0) return ST_OK;      // an empty ray batch
     PointSrc ps; int flags;
     if (int e = render_points(a, ps, flags)) return e;
     ES_REQUIRE(packed && weff, "null weights");
@@ -516,6 +529,7 @@ int es_render_forward(const es_render_args* a, const float* packed, const float*
     return composite(render_composite_args(a, flags), 0, st);
 }
 int es_render_backward(const es_render_args* a, const float* packed, const float* weff, float* dweff, void* stream) {
+    if (a && a->c.N == 0) return ST_OK;      // an empty ray batch
     PointSrc ps; int flags;
     if (int e = render_points(a, ps, flags)) return e;
     ES_REQUIRE(packed && weff && dweff, "null weights / gradient buffer");
@@ -537,8 +551,8 @@ int64_t es_march_scratch_floats(int N, int n_steps) {
 }
 int es_ray_marching(const float* rays, int N, int n_steps, int n_secant, float tau, int block, const float* packed, const float* weff,
                     int use_deform, float* d_out, float* scratch, void* stream) {
-    ES_REQUIRE(rays && packed && weff && d_out && N >= 0 && n_steps >= 2 && n_secant >= 0, "es_ray_marching arguments");
     if (N == 0) return ST_OK;
+    ES_REQUIRE(rays && packed && weff && d_out && N >= 0 && n_steps >= 2 && n_secant >= 0, "es_ray_marching arguments");
     ES_REQUIRE(scratch != nullptr, "es_ray_marching needs scratch");
     hipStream_t st = (hipStream_t)stream;
     const size_t NP = up64((size_t)N * n_steps), N1 = up64((size_t)N);

@@ -193,3 +193,35 @@ def test_tail_separate_backward_passes():
         torch.cuda.synchronize()
         res.append(_grads(r))
     _close(res[0], res[1])
+
+
+@pytest.mark.parametrize("n", [0, 1, 100])
+def test_reference_sequence_edge_batches(n):
+    """Empty, single-ray and ragged (not a multiple of the 64-point tile) batches through the three calls, stand-alone and in the tail:
+    finite losses, a backward that runs, finite gradients; with an all-zero mask the surface-neighbour term is exactly 0."""
+    import weightgen
+    from gpu_util import renderer_for
+    r = renderer_for(31, "trained", True)
+    r.engine.deterministic = True
+    dev = "cuda"
+    rays = torch.from_numpy(weightgen.make_rays(5, max(n, 1))[:n]).to(dev)
+    tg = {k: torch.from_numpy(v[:n]).to(dev) for k, v in weightgen.make_targets(6, max(n, 1)).items()}
+    got = []
+    for rep in range(2):                      # second pass: the calls' points go into the render's tail (when there are any)
+        for p in r.parameters():
+            p.grad = None
+        ret = r(rays, iter_step=3, perturb_overwrite=False)
+        a, b_, valid = r.errorondepth(rays, d_gt=tg["depth"], mask=tg["mask"], iter_step=3)
+        sn = r.surface_neighbour_error(rays=rays, mask=tg["mask"], iter_step=3, neighbour_rad=0.1)
+        sn0 = r.surface_neighbour_error(rays=rays, mask=torch.zeros_like(tg["mask"]), iter_step=3, neighbour_rad=0.1)
+        assert float(sn0) == 0.0 and tuple(valid.shape) == (n, 1)
+        loss = ret["color_map"].sum() + ret["gradient_o_error"] + a + b_ + sn + sn0
+        assert bool(torch.isfinite(loss)), float(loss)
+        loss.backward()
+        torch.cuda.synchronize()
+        for k, p in r.named_parameters():
+            assert p.grad is None or bool(torch.isfinite(p.grad).all()), k
+        got.append((float(a), float(b_), float(loss)))
+    if n >= 1:
+        assert r._live_tail is not None and r._live_tail[0].used > 0
+        assert got[0][:2] == got[1][:2]
