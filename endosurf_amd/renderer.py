@@ -1343,6 +1343,8 @@ class EndoSurfRenderer(nn.Module):
         n = flat.shape[0]
         C = int(ray_chunk)
         out = {"color": self.engine.empty(n, 3), "depth": self.engine.empty(n, 1), "normal": self.engine.empty(n, 3)}
+        if n == 0:
+            return out
 
         def chunk_forward(r):
             ret = self.render_rays(r, iter_step=iter_step, perturb_overwrite=perturb_overwrite)
