@@ -74,6 +74,13 @@ class WNLinear(nn.Module):
             n = int(np.prod(shape))
             self.register_parameter(name, nn.Parameter(flat[off:off + n].view(shape)))
 
+    replaced = 0          # bumped when a registered parameter is assigned anew: EndoSurfNet drops its cached parameter walk
+
+    def __setattr__(self, name, value):
+        if name in ("bias", "weight_g", "weight_v") and name in self.__dict__.get("_parameters", {}):
+            WNLinear.replaced += 1
+        super().__setattr__(name, value)
+
     def forward(self, *a, **k):
         raise RuntimeError("layers are evaluated by the fused HIP kernels, not individually")
 
@@ -244,7 +251,7 @@ class EndoSurfNet(nn.Module):
         fixed for the life of the model -- ``_rebind`` / ``_apply`` only re-point ``.data`` -- and the renderer's ``_weights()`` walks this
         list several times per call of every public method.)"""
         cached = self.__dict__.get("_ordered")
-        if cached is not None:
+        if cached is not None and self.__dict__.get("_ordered_at") == WNLinear.replaced:
             return list(cached)
         out = []
         for net in P.NET_NAMES:
@@ -255,6 +262,7 @@ class EndoSurfNet(nn.Module):
                 for name in ("bias", "weight_g", "weight_v"):
                     out.append((f"{net}.net.{l}.{name}", getattr(mod.net[l], name)))
         self.__dict__["_ordered"] = tuple(out)
+        self.__dict__["_ordered_at"] = WNLinear.replaced
         self.__dict__["_plist"] = tuple(p for _, p in out)
         var = self.deviation_network.variance
         base = self._layout
@@ -291,7 +299,7 @@ class EndoSurfNet(nn.Module):
         does the full walk once per parameter version and this one at every other call)."""
         base = self._flat.data_ptr()
         slots = self.__dict__.get("_view_slots")
-        if slots is None:
+        if slots is None or self.__dict__.get("_ordered_at") != WNLinear.replaced:
             self.ordered_params()
             slots = self.__dict__["_view_slots"]
         if spot:
@@ -882,7 +890,7 @@ class EndoSurfRenderer(nn.Module):
     def _weights(self):
         m = self.model
         plist = m.__dict__.get("_plist")
-        if plist is None:
+        if plist is None or m.__dict__.get("_ordered_at") != WNLinear.replaced:      # (first call, or a Parameter object was replaced)
             m.ordered_params()
             plist = m.__dict__["_plist"]
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)

@@ -225,6 +225,12 @@ def test_parameter_rebinding_is_detected():
         assert p.data_ptr() == r.model._flat.data_ptr() + 4 * r.model._layout["sdf_network.net.8.bias"][0]
         r.to("cuda")
         assert torch.allclose(r.model.get_sdf_from_observed_space(x, t), s1, atol=0)
+        # a Parameter OBJECT assigned anew (not only its storage): the cached parameter walk is rebuilt and the value folded back
+        lin = r.model.sdf_network.net[8]
+        lin.bias = torch.nn.Parameter(lin.bias.detach().clone() - 0.25)
+        s2 = r.model.get_sdf_from_observed_space(x, t)
+        assert torch.allclose(s2, s0, atol=1e-5)
+        assert lin.bias.data_ptr() == r.model._flat.data_ptr() + 4 * r.model._layout["sdf_network.net.8.bias"][0]
         with pytest.raises(TypeError):
             r.double()
 
