@@ -1218,6 +1218,7 @@ class EndoSurfRenderer(nn.Module):
         if demand <= 0 or chunk or P_ <= 0 or P_ % 64 or eng.split_precision or torch.cuda.is_current_stream_capturing():
             return None
         cap = demand + (-(P_ + demand)) % 128          # workspace rows come in blocks of 128: no row of the last block is left undefined
+        self.tails_made = getattr(self, "tails_made", 0) + 1          # (observability: how many renders hosted later calls' points)
         return _Tail(eng, P_, cap)
 
     def _tail_slot(self, m: int, weff, flags: int, count: bool = True):

@@ -46,17 +46,23 @@ def _plateau_band(runs):
     return float(np.mean(ends)) - tol, float(np.mean(ends)) + tol, ends
 
 
-def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False, lr=5e-4):
+def _train(n_iter, n_rays, weight_seed, sched_seed, eval_its, deterministic=True, split=False, lr=5e-4, reference_sequence=False, stop_at=None,
+           keep=None):
+    """``reference_sequence``: the reference trainer's own call pattern -- renderer(rays), errorondepth, surface_neighbour_error as three
+    calls, torch loss arithmetic, torch.optim.Adam over the parameter tensors -- instead of the fused step."""
     from endosurf_amd.trainer import Trainer, cal_psnr
     r = renderer_for(weight_seed, "init", True)
     r.engine.deterministic = deterministic
     r.engine.split_precision = split
-    tr = Trainer(r, lr=lr, n_iter=n_iter, warm_up_end=max(n_iter // 10, 1), lr_alpha=0.05, fused=True)
+    if keep is not None:
+        keep.append(r)
+    tr = Trainer(r, lr=lr, n_iter=n_iter, warm_up_end=max(n_iter // 10, 1), lr_alpha=0.05, fused=not reference_sequence,
+                 flat_adam=not reference_sequence)
     sched = synth_scene.schedule(sched_seed, n_iter, n_rays)
     ev = {k: torch.from_numpy(v).cuda() for k, v in synth_scene.eval_batch().items()}
     eval_its = set(int(i) for i in eval_its)
     curve, losses = [], []
-    for it in range(1, n_iter + 1):
+    for it in range(1, (stop_at or n_iter) + 1):
         b = {k: torch.from_numpy(v).cuda() for k, v in sched[it - 1].items()}
         tr.update_learning_rate(it)
         loss, _, _ = tr.train_step(b, it, u_perturb=b["u_perturb"], u_neigh=b["u_neigh"])
@@ -98,6 +104,25 @@ def test_psnr_curve_matches_reference_to_the_plateau():
     # (3) losses: identical first step, same level at the end
     assert abs(losses[0] - ref_loss[0]) < 2e-3 * max(1.0, abs(ref_loss[0]))
     assert abs(np.mean(losses[-100:]) - np.mean(ref_loss[-100:])) < 0.1 * abs(np.mean(ref_loss[-100:])) + 0.005
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="reference PSNR curve not generated (tools/psnr_reference.py)")
+def test_psnr_early_curve_through_the_reference_call_sequence():
+    """The reference trainer's OWN call sequence through the drop-in (three renderer calls, torch.optim.Adam; from the second step on the
+    auxiliary calls' points ride in the render workspace's tail) follows the reference's PSNR curve through the first 150 iterations of
+    the schedule as the fused step does: identical start, < 0.1 dB up to iteration 60, and the same losses as the fused step's."""
+    g = np.load(GOLD)
+    n_iter, n_rays, ref_curve = int(g["n_iter"]), int(g["n_rays"]), g["curve"]
+    its = ref_curve[ref_curve[:, 0] <= 150, 0]
+    keep = []
+    curve, losses = _train(n_iter, n_rays, int(g["weight_seed"]), int(g["sched_seed"]), its, reference_sequence=True, stop_at=150, keep=keep)
+    assert keep[0].tails_made >= 148                    # every step but the first went through the render workspace's tail
+    d = curve[:, 1] - ref_curve[:len(curve), 1]
+    assert abs(d[0]) < 0.02 and np.max(np.abs(d[its <= 60])) < 0.1, d
+    fused_curve, fused_losses = _train(n_iter, n_rays, int(g["weight_seed"]), int(g["sched_seed"]), its, stop_at=150)
+    assert abs(losses[0] - fused_losses[0]) < 1e-5 * max(1.0, abs(fused_losses[0]))
+    assert np.max(np.abs(losses[:20] - fused_losses[:20])) < 2e-3 * np.max(np.abs(fused_losses[:20]))
+    assert np.max(np.abs(curve[:, 1] - fused_curve[:, 1])[its <= 60]) < 0.1
 
 
 def test_psnr_run_is_reproducible_in_deterministic_mode():
