@@ -623,14 +623,15 @@ class ReferenceLoop:
 
     W = dict(color=1.0, depth=1.0, sdf=1.0, angle=0.1, eikonal=0.1, surf_neig=0.1)      # base_pull.yml:23-29
 
-    def __init__(self, ctx, logging=False, config_id=2, flat_adam=False):
+    def __init__(self, ctx, logging=False, config_id=2, flat_adam=False, defer_eod=True):
         import torch
         from endosurf_amd import EndoSurfRenderer
         from endosurf_amd.trainer import SyntheticScene
         cfg = CONFIGS[config_id]
         torch.manual_seed(0)
         self.cfg, self.logging = cfg, bool(logging)
-        self.renderer = EndoSurfRenderer(render_cfg(cfg), dict(NET_CFG, use_deform=cfg["use_deform"]), device=ctx.dev)
+        self.renderer = EndoSurfRenderer(dict(render_cfg(cfg), defer_errorondepth=bool(defer_eod)), dict(NET_CFG, use_deform=cfg["use_deform"]),
+                                         device=ctx.dev)
         train_params = self.renderer.get_train_params()
         grad_vars = []
         for key in train_params.keys():
@@ -908,6 +909,7 @@ def main():
                     help="profiling aid: run ONLY the reference trainer's own loop through the drop-in (ReferenceLoop) and print its record")
     ap.add_argument("--no-graph", action="store_true", help="frame mode: eager launches instead of the captured hipGraph")
     ap.add_argument("--schedule", default="fused", choices=["fused", "plain"])
+    ap.add_argument("--no-defer-eod", action="store_true", help="--refseq-only: render_cfg['defer_errorondepth'] = False (A/B of the deferred errorondepth evaluation)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the extra early-exit timing and the extras (profiling runs: every launch of the process then belongs to the "
                          "headline workload)")
@@ -964,7 +966,7 @@ def main():
                 else dict(pinned=False, reason="one rank" if world == 1 else "--no-pin"))
 
     if args.refseq_only:
-        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging", flat_adam=args.refseq_only == "flat_adam")
+        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging", flat_adam=args.refseq_only == "flat_adam", defer_eod=not args.no_defer_eod)
         print(json.dumps(loop.measure(args.warmup, args.steps)), flush=True)
         return
 

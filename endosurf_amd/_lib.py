@@ -79,7 +79,7 @@ PROTOTYPES = {
     "es_point_workspace_offset": (C.c_int64, [_I, _I, _I]),
     "es_point_forward": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _P]),
     "es_point_forward_rows": (_I, [C.POINTER(es_points), _P, _P, _P, _I, _I, _I, _I, _P]),
-    "es_eod_points": (_I, [_P, _P, _I, _P, _P, _P]),
+    "es_eod_points": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "es_sn_points": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
     "es_eod_loss": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "es_eod_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),

@@ -25,7 +25,7 @@ int point_forward(const PointSrc& src, const float* packed, const float* weff, f
                   const void* packed_x3 = nullptr);
 int point_forward_rows(const PointSrc& src, const float* packed, const float* weff, float* ws, int flags, int m_color, int row0, int nrows,
                        hipStream_t st);
-int eod_points(const float* rays, const float* depth_gt, int N, float* x, float* t, hipStream_t st);
+int eod_points(const float* rays, const float* depth_gt, const float* mask, int N, float* x, float* t, float* inside, hipStream_t st);
 int sn_points(const float* rays, const float* mask, const float* d_i, const float* u, float rad, int N, float* x, float* t, unsigned char* valid,
               hipStream_t st);
 int eod_loss(const float* rays, const float* pts, const float* mask, const float* sdf, const float* go, int N, float* out, float* inside, hipStream_t st);
@@ -282,9 +282,10 @@ int es_point_forward_rows(const es_points* pts, const float* packed, const float
     if (int e = check_mcolor(pts, flags, m_color)) return e;
     return point_forward_rows(to_src(pts), packed, weff, ws, flags, m_color, row0, nrows, (hipStream_t)stream);
 }
-int es_eod_points(const float* rays, const float* depth_gt, int N, float* x, float* t, void* stream) {
+int es_eod_points(const float* rays, const float* depth_gt, const float* mask, int N, float* x, float* t, float* inside, void* stream) {
     ES_REQUIRE(N >= 0 && (N == 0 || (rays && depth_gt && x && t)), "es_eod_points buffers");
-    return eod_points(rays, depth_gt, N, x, t, (hipStream_t)stream);
+    ES_REQUIRE(inside == nullptr || mask != nullptr || N == 0, "es_eod_points: the inside mask needs the ray mask");
+    return eod_points(rays, depth_gt, mask, N, x, t, inside, (hipStream_t)stream);
 }
 int es_sn_points(const float* rays, const float* mask, const float* d_i, const float* u, float rad, int N, float* x, float* t,
                  unsigned char* valid, void* stream) {

@@ -15,15 +15,18 @@ __device__ __forceinline__ float sgn1(float x) { return x > 0.f ? 1.f : (x < 0.f
 
 // ---- points ---------------------------------------------------------------------------------------------------------------------------
 // errorondepth points (endosurf.py:297-300): x = o + d / (d.z + 1e-6) * d_gt, t = rays[:, 8]
-__global__ __launch_bounds__(256) void k_eod_points(const float* __restrict__ rays, const float* __restrict__ depth_gt, int N,
-                                                    float* __restrict__ x, float* __restrict__ t) {
+// (optionally also inside = (|x| < 1) * mask, endosurf.py:306-309: the one output of errorondepth that does not need the networks)
+__global__ __launch_bounds__(256) void k_eod_points(const float* __restrict__ rays, const float* __restrict__ depth_gt, const float* __restrict__ mask,
+                                                    int N, float* __restrict__ x, float* __restrict__ t, float* __restrict__ inside) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float* r = rays + 9 * (size_t)i;
     const float inv = r[5] + 1e-6f, dg = depth_gt[i];
+    float p[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x[3 * (size_t)i + c] = r[c] + (r[3 + c] / inv) * dg;
+    for (int c = 0; c < 3; ++c) { p[c] = r[c] + (r[3 + c] / inv) * dg; x[3 * (size_t)i + c] = p[c]; }
     t[i] = r[8];
+    if (inside != nullptr) inside[i] = (sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) < 1.f ? 1.f : 0.f) * mask[i];
 }
 // surface points and their neighbours (endosurf.py:323-332): rows [0,N) o + d_z * d_i (d_i = 0 where the ray has no valid hit), rows
 // [N,2N) the same + (u - 0.5) * rad; valid = isfinite(d_i) && d_i != 0 && mask == 1
@@ -171,9 +174,9 @@ __global__ __launch_bounds__(256) void k_copy2(float* __restrict__ da, const flo
 
 static inline dim3 g256(long long n) { return dim3((unsigned)((n + 255) / 256)); }
 
-int eod_points(const float* rays, const float* depth_gt, int N, float* x, float* t, hipStream_t st) {
+int eod_points(const float* rays, const float* depth_gt, const float* mask, int N, float* x, float* t, float* inside, hipStream_t st) {
     if (N <= 0) return ST_OK;
-    hipLaunchKernelGGL(k_eod_points, g256(N), dim3(256), 0, st, rays, depth_gt, N, x, t);
+    hipLaunchKernelGGL(k_eod_points, g256(N), dim3(256), 0, st, rays, depth_gt, mask, N, x, t, inside);
     return hip_last("eod_points");
 }
 int sn_points(const float* rays, const float* mask, const float* d_i, const float* u, float rad, int N, float* x, float* t, unsigned char* valid,

@@ -598,6 +598,7 @@ class _Tail:
         self.g_sdf, self.g_go = buf[4 * cap:5 * cap].view(cap, 1), buf[5 * cap:].view(cap, 3)
         self.gbuf = buf[4 * cap:]                     # both adjoint buffers: cleared again behind every backward that consumed them
         self.pctx, self.weff, self.flags = None, None, 0
+        self.pending = None                           # a deferred errorondepth evaluation placed in these rows (_PendingEod)
 
     def room(self, m64: int, weff, flags: int) -> bool:
         return self.pctx is not None and self.weff is weff and self.flags == flags and self.used + m64 <= self.cap
@@ -630,6 +631,102 @@ class _TailEvalFn(torch.autograd.Function):
             _lib.check(eng.lib.es_copy2(_lib.ptr(tail.g_sdf[off:]), _lib.ptr(d_sdf), m if d_sdf is not None else 0,
                                         _lib.ptr(tail.g_go[off:]), _lib.ptr(d_go), 3 * m if d_go is not None else 0, eng.st()), "es_copy2")
         return None, None, None, None, None
+
+
+class _Lazy(torch.Tensor):
+    """A result whose producing launches have not been ISSUED yet: every torch function that touches it first issues them (on the calling
+    thread, in program order: whatever reads the value is enqueued behind them), then runs on the plain tensor.  Attribute getters
+    (``.shape``, ``.dtype``, ``.requires_grad``, ``.grad_fn`` ...) do not trigger.  Used by ``errorondepth``: see ``_PendingEod``."""
+
+    @staticmethod
+    def wrap(t: torch.Tensor, pending):
+        r = t.as_subclass(_Lazy)
+        r._es_pending = pending
+        return r
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        meta = getattr(func, "__name__", "") == "__get__"
+
+        def plain(a):
+            if isinstance(a, _Lazy):
+                p = a.__dict__.get("_es_pending")
+                if p is not None and not meta:
+                    p.force()
+                return a.as_subclass(torch.Tensor)
+            if isinstance(a, (list, tuple)):
+                return type(a)(plain(b) for b in a)
+            return a
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[plain(a) for a in args], **{k: plain(v) for k, v in kwargs.items()})
+
+
+class _PendingEod:
+    """``errorondepth``'s network evaluation + reductions, not issued yet.  The reference trainer reads ``sdf_loss`` / ``angle_loss`` only
+    after it has called ``surface_neighbour_error`` (trainer_endosurf.py:139-162), whose own colour-less points take the rows right
+    behind these in the render workspace's tail: the two evaluations then go out as ONE launch chain (deformation on 16-point tiles, SDF +
+    VJP on 32-row tiles: 96 workgroups at one tile's latency instead of 32, then 64, at one tile's latency EACH: 0.37 ms per step).
+    ``force()`` issues whatever is still missing; it is called by the next evaluation into the same tail (which folds these rows into
+    its launch first), by the first torch function that touches a result (``_Lazy``), by this node's backward and by the render's
+    backward -- whichever comes first; so nothing depends on the caller's order of calls, only the saving does."""
+
+    def __init__(self, renderer, tail, off, n, rays, mask, weff, packed):
+        eng = renderer.engine
+        self.renderer, self.tail, self.off, self.n, self.m64 = weakref.ref(renderer), tail, int(off), int(n), (int(n) + 63) // 64 * 64
+        self.rays, self.mask, self.weff, self.packed, self.eng = rays, mask, weff, packed, eng
+        self.out, self.inside = eng.empty(3), eng.empty(n, 1)
+        self.sdf, self.go = eng.empty(n, 1), eng.empty(n, 3)
+        self.rows_done, self.done = False, False
+        self.stream = torch.cuda.current_stream(eng.device)
+
+    def force(self):
+        if self.done:
+            return
+        self.done = True
+        eng, tail = self.eng, self.tail
+        if tail.pending is self:
+            tail.pending = None
+        cur = torch.cuda.current_stream(eng.device)
+        with torch.no_grad(), torch.cuda.stream(self.stream):          # (on the stream the call was made on, whoever triggers it)
+            if tail.pctx is None:
+                raise RuntimeError("errorondepth's deferred evaluation outlived the render workspace it was placed in")
+            if not self.rows_done:
+                eng.point_forward_rows(tail.pctx, self.weff, self.packed, tail.P + self.off, self.m64)
+                self.rows_done = True
+            r0, n = tail.P + self.off, self.n
+            _lib.check(eng.lib.es_copy2(_lib.ptr(self.sdf), _lib.ptr(tail.pctx.view("sdf")[r0:]), n, _lib.ptr(self.go),
+                                        _lib.ptr(tail.pctx.view("go")[r0:]), 3 * n, eng.st()), "es_copy2")
+            _lib.check(eng.lib.es_eod_loss(_lib.ptr(self.rays), _lib.ptr(tail.aux_x[self.off:]), _lib.ptr(self.mask), _lib.ptr(self.sdf),
+                                           _lib.ptr(self.go), n, _lib.ptr(self.out), _lib.ptr(self.inside), eng.st()), "es_eod_loss")
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+
+
+class _LazyEodFn(torch.autograd.Function):
+    """(sdf_error, angle_error) of a ``_PendingEod``: the autograd node exists from the call on, its values from ``force()`` on.  Like
+    ``_TailEvalFn`` it hangs on the render's token and deposits the points' adjoints in the tail for the render's backward."""
+
+    @staticmethod
+    def forward(ctx, token, pending: _PendingEod):
+        ctx.pending = pending
+        ctx.set_materialize_grads(False)
+        return pending.out[0], pending.out[1]
+
+    @staticmethod
+    def backward(ctx, g_sdf_err, g_ang_err):
+        p = ctx.pending
+        if g_sdf_err is None and g_ang_err is None:
+            return None, None
+        p.force()
+        eng, tail, n = p.eng, p.tail, p.n
+        f = lambda g: None if g is None else g.detach().to(torch.float32).reshape(1)
+        ga, gb = f(g_sdf_err), f(g_ang_err)
+        _lib.check(eng.lib.es_eod_loss_backward(_lib.ptr(p.rays), _lib.ptr(p.inside), _lib.ptr(p.sdf), _lib.ptr(p.go), _lib.ptr(p.out), _lib.ptr(ga),
+                                                _lib.ptr(gb), n, _lib.ptr(tail.g_sdf[p.off:]), _lib.ptr(tail.g_go[p.off:]), eng.st()),
+                   "es_eod_loss_backward")
+        return None, None
 
 
 class _EodLossFn(torch.autograd.Function):
@@ -778,6 +875,8 @@ class _RenderFn(torch.autograd.Function):
         eng = ctx.eng
         tail = ctx.tail
         if tail is not None:
+            if tail.pending is not None:          # (a deferred errorondepth nobody has read: its rows must be defined before the backward)
+                tail.pending.force()
             # the later calls' points behind the samples: their nodes have run (they depend on this one through the token) and left
             # their adjoints in the tail's buffers; rows nobody claimed are evaluated now, with zero adjoints
             if tail.pctx is not None and tail.used < tail.cap:
@@ -1240,7 +1339,16 @@ class EndoSurfRenderer(nn.Module):
         tail, off = slot[0], slot[1]
         m64 = (m + 63) // 64 * 64
         tail.used = off + m64
-        self.engine.point_forward_rows(tail.pctx, weff, packed, tail.P + off, m64)
+        pend = tail.pending
+        if pend is not None and not pend.done and not pend.rows_done and pend.off + pend.m64 == off and pend.stream == torch.cuda.current_stream(self.device):
+            # errorondepth's deferred rows sit right in front of these: ONE launch chain evaluates both pieces
+            self.engine.point_forward_rows(tail.pctx, weff, packed, tail.P + pend.off, pend.m64 + m64)
+            pend.rows_done = True
+            pend.force()
+        else:
+            if pend is not None:
+                pend.force()
+            self.engine.point_forward_rows(tail.pctx, weff, packed, tail.P + off, m64)
         return _TailEvalFn.apply(self._live_tail[1], tail, self.engine, off, m)
 
     def _aux_buffers(self, m: int):
@@ -1254,21 +1362,53 @@ class EndoSurfRenderer(nn.Module):
 
     @_on_device
     def errorondepth(self, rays, d_gt, mask, iter_step=0):
-        """reference errorondepth (endosurf.py:289-317): three library launches (points, evaluation, reductions) + the evaluation's own."""
-        rays = self._rays32(rays)
-        pts, time = self._eod_points(rays, d_gt)
-        sdf, gradient_o = self._point_eval(pts, time)
-        return self._eod_loss(rays, pts, mask, sdf, gradient_o)
+        """reference errorondepth (endosurf.py:289-317): points, evaluation, reductions as library launches.
 
-    def _eod_points(self, rays, d_gt):
-        """o + d / (d.z + 1e-6) * d_gt and the rays' times (endosurf.py:297-300), one launch (es_eod_points)."""
+        When the points go into the tail of a live render (the reference trainer's step from its second iteration on) the network
+        evaluation and the reductions are DEFERRED (``_PendingEod``): ``inside_masksphere`` -- which needs no network -- comes from the
+        points launch right away, ``sdf_error`` / ``angle_error`` are ``_Lazy`` tensors whose launches go out when something first
+        touches them, or -- the reference's order of calls -- together with ``surface_neighbour_error``'s evaluation, as one launch chain
+        instead of two (``render_cfg["defer_errorondepth"] = False``: evaluate at once)."""
+        rays = self._rays32(rays)
         N = rays.shape[0]
-        x, t = self._aux_buffers(N)
+        weff, packed = self._weights()
+        flags = self._flags(weff)
+        slot = None
+        if (bool(self.render_cfg.get("defer_errorondepth", True)) and (flags & _lib.PF_SAVE) and N > 0 and torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            slot = self._tail_slot(N, weff, flags, count=False)          # (counted below / by _point_eval: once)
+        if slot is None:
+            pts, time, inside = self._eod_points(rays, d_gt, mask)
+            sdf, gradient_o = self._point_eval(pts, time)
+            return self._eod_loss(rays, pts, mask, sdf, gradient_o)
+        tail, off = slot[0], slot[1]
+        self._aux_demand = getattr(self, "_aux_demand", 0) + (N + 63) // 64 * 64
+        if tail.pending is not None:
+            tail.pending.force()
+        inside = self._eod_points(rays, d_gt, mask, into=(slot[2], slot[3]))[2]
+        tail.used = off + (N + 63) // 64 * 64
+        pend = _PendingEod(self, tail, off, N, rays, mask.detach().to(torch.float32).reshape(-1).contiguous(), weff, packed)
+        tail.pending = pend
+        a, b = _LazyEodFn.apply(self._live_tail[1], pend)
+        return _Lazy.wrap(a, pend), _Lazy.wrap(b, pend), inside
+
+    def _eod_points(self, rays, d_gt, mask=None, into=None):
+        """o + d / (d.z + 1e-6) * d_gt and the rays' times (endosurf.py:297-300) and -- with ``mask`` -- inside_masksphere [N,1]
+        (:306-309), one launch (es_eod_points).  ``into``: (x, t) buffers to write the points to (rows of a render's tail)."""
+        N = rays.shape[0]
+        x, t = into if into is not None else self._aux_buffers(N)
         d = d_gt.detach().to(torch.float32).reshape(-1).contiguous()
         if d.numel() != N:
             raise ValueError("errorondepth expects one ground-truth depth per ray")
-        _lib.check(self.engine.lib.es_eod_points(_lib.ptr(rays), _lib.ptr(d), N, _lib.ptr(x), _lib.ptr(t), self.engine.st()), "es_eod_points")
-        return x, t
+        inside = m = None
+        if mask is not None:
+            m = mask.detach().to(torch.float32).reshape(-1).contiguous()
+            if m.numel() != N:
+                raise ValueError("errorondepth expects one mask value per ray")
+            inside = self.engine.empty(N, 1)
+        _lib.check(self.engine.lib.es_eod_points(_lib.ptr(rays), _lib.ptr(d), _lib.ptr(m), N, _lib.ptr(x), _lib.ptr(t), _lib.ptr(inside),
+                                                 self.engine.st()), "es_eod_points")
+        return (x, t, inside) if mask is not None else (x, t)
 
     def _eod_loss(self, rays, pts, mask, sdf, gradient_o):
         """(sdf_error, angle_error, inside_masksphere [N,1]) (endosurf.py:302-317; the angle term is not masked, like the reference)."""

@@ -225,3 +225,60 @@ def test_reference_sequence_edge_batches(n):
     if n >= 1:
         assert r._live_tail is not None and r._live_tail[0].used > 0
         assert got[0][:2] == got[1][:2]
+
+
+def test_deferred_errorondepth_semantics():
+    """``errorondepth`` into a live render's tail returns lazily evaluated results (renderer._Lazy / _PendingEod): whatever touches them
+    first issues the launches.  Read at once, read after ``surface_neighbour_error`` (the reference's order: ONE launch chain for both
+    calls' points), never read, used directly as the loss: same values bit for bit, same gradients as the eager evaluation."""
+    from endosurf_amd.renderer import _Lazy
+    c = load_case("trained_deform")
+    b, u, un = _batch(c)
+    it = int(c["meta/iter_step"])
+    N = b["rays"].shape[0]
+    need = (N + 63) // 64 * 64 + (2 * N + 63) // 64 * 64
+
+    def run(mode, defer=True):
+        r = renderer_for_case(c)
+        r.render_cfg["defer_errorondepth"] = defer
+        r.engine.deterministic = True
+        r.perturb = u is not None
+        r._aux_demand = need
+        ret = r(b["rays"], iter_step=it, u_perturb=u)
+        tail = r._live_tail[0]
+        a, bb, valid = r.errorondepth(b["rays"], d_gt=b["depth"], mask=b["mask"], iter_step=it)
+        assert isinstance(a, _Lazy) == defer and a.requires_grad and tuple(a.shape) == () and a.dtype == torch.float32      # (getters do not force)
+        assert (tail.pending is not None) == defer
+        early = None
+        if mode == "read_at_once":
+            early = (a.item(), float(bb))
+            assert tail.pending is None
+        sn = r.surface_neighbour_error(rays=b["rays"], mask=b["mask"], iter_step=it, neighbour_rad=0.1, u_neigh=un)
+        if mode != "never_read":
+            assert tail.pending is None                                       # sn's evaluation took errorondepth's rows along
+        base = ret["color_map"].sum() + (ret["depth_map"] * valid).sum() + 0.1 * sn
+        if mode == "never_read":
+            loss = base
+        elif mode == "loss_is_lazy":
+            loss = a                                                          # Tensor.backward on the lazy tensor itself
+        else:
+            loss = base + a + 0.1 * bb
+        vals = (float(a.detach().cpu().numpy()), bb.item()) if mode != "never_read" else None
+        loss.backward()
+        torch.cuda.synchronize()
+        if early is not None:
+            assert early == vals
+        return vals, _grads(r), type(torch.stack([a, bb]))
+
+    ref_vals, ref_g, _ = run("reference_order", defer=False)
+    for mode in ("reference_order", "read_at_once"):
+        vals, g, stacked = run(mode)
+        assert vals == ref_vals and stacked is torch.Tensor
+        _close(ref_g, g, tol=1e-6)
+    # never read: the render's backward defines the rows; the gradient is that of the loss without the two terms
+    _, g_never, _ = run("never_read")
+    _, g_never_ref, _ = run("never_read", defer=False)
+    _close(g_never_ref, g_never, tol=1e-6)
+    _, g_lazy, _ = run("loss_is_lazy")
+    _, g_lazy_ref, _ = run("loss_is_lazy", defer=False)
+    _close(g_lazy_ref, g_lazy, tol=1e-6)
