@@ -638,6 +638,13 @@ class _Lazy(torch.Tensor):
     thread, in program order: whatever reads the value is enqueued behind them), then runs on the plain tensor.  Attribute getters
     (``.shape``, ``.dtype``, ``.requires_grad``, ``.grad_fn`` ...) do not trigger.  Used by ``errorondepth``: see ``_PendingEod``."""
 
+    # what may be asked of the tensor without its value (everything else -- including the ``.data`` / ``.T`` getters, which hand out
+    # aliases of the storage -- issues the launches first)
+    _META = frozenset(("shape", "dtype", "device", "requires_grad", "grad_fn", "is_cuda", "is_leaf", "ndim", "layout", "names", "is_sparse",
+                       "is_quantized", "is_meta", "output_nr", "_version", "grad", "is_cpu", "itemsize", "nbytes"))
+    _META_FN = frozenset(("dim", "size", "numel", "ndimension", "nelement", "is_contiguous", "is_floating_point", "is_complex", "stride",
+                          "element_size", "get_device"))
+
     @staticmethod
     def wrap(t: torch.Tensor, pending):
         r = t.as_subclass(_Lazy)
@@ -647,7 +654,8 @@ class _Lazy(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        meta = getattr(func, "__name__", "") == "__get__"
+        name = getattr(func, "__name__", "")
+        meta = (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in cls._META) or name in cls._META_FN
 
         def plain(a):
             if isinstance(a, _Lazy):
@@ -674,18 +682,27 @@ class _PendingEod:
 
     def __init__(self, renderer, tail, off, n, rays, mask, weff, packed):
         eng = renderer.engine
-        self.renderer, self.tail, self.off, self.n, self.m64 = weakref.ref(renderer), tail, int(off), int(n), (int(n) + 63) // 64 * 64
+        # (weak references: the tail is kept alive by the render's autograd node, which every reader of the results reaches through this
+        # evaluation's own node; a strong one would close a cycle with ``tail.pending`` around the 6.7 GB workspace)
+        self.renderer, self._tail, self.off, self.n, self.m64 = weakref.ref(renderer), weakref.ref(tail), int(off), int(n), (int(n) + 63) // 64 * 64
         self.rays, self.mask, self.weff, self.packed, self.eng = rays, mask, weff, packed, eng
         self.out, self.inside = eng.empty(3), eng.empty(n, 1)
         self.sdf, self.go = eng.empty(n, 1), eng.empty(n, 3)
         self.rows_done, self.done = False, False
         self.stream = torch.cuda.current_stream(eng.device)
 
+    @property
+    def tail(self):
+        t = self._tail()
+        if t is None:
+            raise RuntimeError("errorondepth's deferred evaluation outlived the render it was placed in")
+        return t
+
     def force(self):
         if self.done:
             return
-        self.done = True
         eng, tail = self.eng, self.tail
+        self.done = True
         if tail.pending is self:
             tail.pending = None
         cur = torch.cuda.current_stream(eng.device)

@@ -251,8 +251,11 @@ def test_deferred_errorondepth_semantics():
         assert (tail.pending is not None) == defer
         early = None
         if mode == "read_at_once":
+            assert a.dim() == 0 and a.numel() == 1 and tail.pending is not None      # (metadata methods do not force either)
+            alias = a.data                                                    # a getter that hands out the storage: forces
+            assert tail.pending is None and not isinstance(alias, _Lazy)
             early = (a.item(), float(bb))
-            assert tail.pending is None
+            assert float(alias) == early[0]
         sn = r.surface_neighbour_error(rays=b["rays"], mask=b["mask"], iter_step=it, neighbour_rad=0.1, u_neigh=un)
         if mode != "never_read":
             assert tail.pending is None                                       # sn's evaluation took errorondepth's rows along
