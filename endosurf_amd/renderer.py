@@ -1333,6 +1333,11 @@ class EndoSurfRenderer(nn.Module):
         eng = self.engine
         if demand <= 0 or chunk or P_ <= 0 or P_ % 64 or eng.split_precision or torch.cuda.is_current_stream_capturing():
             return None
+        # (every tail row costs a full workspace row, ~100 KB: never more than a quarter of the render's own rows (4 096 for small renders), whatever was asked for --
+        # the reference's three calls ask for 3 / 64 of them; what does not fit is evaluated stand-alone as before)
+        demand = min(demand, max(P_ // 4, 4096) // 64 * 64)
+        if demand <= 0:
+            return None
         cap = demand + (-(P_ + demand)) % 128          # workspace rows come in blocks of 128: no row of the last block is left undefined
         self.tails_made = getattr(self, "tails_made", 0) + 1          # (observability: how many renders hosted later calls' points)
         return _Tail(eng, P_, cap)

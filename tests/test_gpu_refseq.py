@@ -94,6 +94,10 @@ def test_tail_overflow_and_unclaimed_rows():
     _close(g0, g2)
     for k, g in g2.items():
         assert bool(torch.isfinite(g).all()), k
+    # an absurd demand (a caller that evaluated a million points after the last render) is capped: a tail row costs a workspace row
+    _, t3, g3, tail = _step(r, b, u, un, it, use, demand=1 << 20)
+    assert tail is not None and tail.cap <= 4096 + 128 and t0 == t3
+    _close(g0, g3)
 
 
 def test_tail_second_render_before_backward():
