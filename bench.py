@@ -966,7 +966,8 @@ def main():
                 else dict(pinned=False, reason="one rank" if world == 1 else "--no-pin"))
 
     if args.refseq_only:
-        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging", flat_adam=args.refseq_only == "flat_adam", defer_eod=not args.no_defer_eod)
+        loop = ReferenceLoop(ctx, logging=args.refseq_only == "logging", flat_adam=args.refseq_only == "flat_adam", defer_eod=not args.no_defer_eod,
+                             config_id=args.config if args.config in (2, 3, 4) else 2)
         print(json.dumps(loop.measure(args.warmup, args.steps)), flush=True)
         return
 
