@@ -81,8 +81,13 @@ class WNLinear(nn.Module):
             WNLinear.replaced += 1
         super().__setattr__(name, value)
 
-    def forward(self, *a, **k):
-        raise RuntimeError("layers are evaluated by the fused HIP kernels, not individually")
+    def forward(self, x):
+        """One weight-normed linear layer on its own, y = x (g v / |v|_row)^T + b: what ``model.<net>.net[l](x)`` gives in the reference
+        (nn.utils.weight_norm(nn.Linear), utils.py:57-58 / :108-109).  Not part of the hot path -- the fused kernels evaluate whole
+        networks -- so this is plain torch arithmetic on the parameter views, differentiable like the reference's."""
+        v = self.weight_v
+        w = self.weight_g * v / torch.linalg.norm(v, dim=1, keepdim=True)
+        return torch.nn.functional.linear(x.to(v.dtype), w, self.bias)
 
 
 class _MLP(nn.Module):

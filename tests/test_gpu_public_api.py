@@ -377,3 +377,19 @@ def test_model_forward_is_differentiable_wrt_its_inputs(mode, use_deform):
     (g1,) = torch.autograd.grad(s, i32b, retain_graph=True)
     (g2,) = torch.autograd.grad(s, i32b)
     assert float((g1 - g2).abs().max()) <= 1e-6 * float(g1.abs().max()) and float((g1 - i32.grad).abs().max()) <= 1e-5 * float(g1.abs().max())
+
+
+def test_single_layer_call_matches_the_weight_normed_linear():
+    """``model.sdf_network.net[l](x)``: one weight-normed nn.Linear of the reference (utils.py:57-58) -- plain torch on the parameter
+    views, against the oracle's effective weight; gradients reach the parameters."""
+    from oracle import endosurf_oracle as O
+    c = load_case("trained_deform")
+    r = renderer_for_case(c)
+    lin = r.model.sdf_network.net[2]
+    x = torch.randn(17, lin.weight_v.shape[1], device="cuda")
+    y = lin(x)
+    W = O.effective_weight(lin.weight_g.detach().double().cpu(), lin.weight_v.detach().double().cpu())
+    ref = x.double().cpu() @ W.t() + lin.bias.detach().double().cpu()
+    assert float((y.detach().double().cpu() - ref).abs().max()) < 1e-5
+    y.sum().backward()
+    assert lin.weight_v.grad is not None and lin.weight_g.grad is not None and float(lin.bias.grad.sum()) == 17 * lin.bias.numel()
