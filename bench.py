@@ -751,6 +751,26 @@ class ReferenceLoop:
                                    "foreach" if opt.param_groups[0].get("foreach") in (None, True) and not opt.param_groups[0].get("fused") else "fused")))
 
 
+def refseq_launches_from_profile():
+    """Kernel launches per step of the reference loop from the newest committed rocprofv3 kernel statistics of ``bench.py --refseq-only
+    plain --steps 10 --warmup 3`` (tools/profile_round.sh: 3 warm-up + 10 timed + 3 instrumented + 1 + 10 early-exit steps = 27 steps):
+    all kernels, the library's (es::), the framework's element-wise / reduction kernels (at::native, of which the optimiser's multi-tensor
+    ones).  None if no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_plain_kernel_stats.csv")), reverse=True)
+    if not files:
+        return None
+    rows = list(csv.DictReader(open(files[0])))
+    n = 27.0
+    cnt = lambda pred: round(sum(int(r["Calls"]) for r in rows if pred(r["Name"])) / n, 1)
+    ms = lambda pred: round(sum(float(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / 1e6 / n, 3)
+    return dict(source=os.path.basename(files[0]), steps_profiled=int(n), all=cnt(lambda s: True), library=cnt(lambda s: "es::" in s),
+                framework=cnt(lambda s: "at::native" in s), of_which_optimizer=cnt(lambda s: "multi_tensor" in s),
+                kernel_ms_per_step=dict(all=ms(lambda s: True), library=ms(lambda s: "es::" in s), framework=ms(lambda s: "at::native" in s),
+                                        of_which_optimizer=ms(lambda s: "multi_tensor" in s)))
+
+
 def reference_call_sequence(ctx, args, steps=None):
     """extras.reference_call_sequence: the reference trainer's own loop through the drop-in, config 2, same synthetic
     batches as the headline -- without and with the reference's per-step logging traffic."""
@@ -765,6 +785,7 @@ def reference_call_sequence(ctx, args, steps=None):
         loop = None
         gc.collect()
         torch.cuda.empty_cache()
+    out["launches_per_step"] = refseq_launches_from_profile()
     out["what"] = ("the reference trainer's own step (trainer_endosurf.py:60-72, 94-104, 106-181, 183-203) with "
                    "src.renderer.endosurf.EndoSurfRenderer replaced by endosurf_amd.EndoSurfRenderer and nothing else: renderer(rays) -> "
                    "errorondepth -> surface_neighbour_error as three calls, torch loss arithmetic, loss.backward(), torch.optim.Adam.step() "
