@@ -661,6 +661,9 @@ class ReferenceLoop:
         color_pred = ret["color_map"]
         color_error = (color_pred - color_gt) * color_mask_gt
         color_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction="sum") / (color_mask_gt.sum() + 1e-10)
+        if self.logging:          # cal_psnr -> tensor2array right here, as in the reference (:137): the host waits for the render's forward
+            a, b, m = (t.detach().cpu().numpy() for t in (color_pred, color_gt, color_mask_gt))
+            _psnr = 20.0 * np.log10(1.0 / (((a - b) ** 2 * m).sum() / ((np.sum(m) + 1e-10) * 3.0)) ** 0.5)
         sdf_loss, angle_loss, valid_depth_region = r.errorondepth(rays, d_gt=depth_gt, mask=mask_gt, iter_step=global_step)
         depth_pred = ret["depth_map"]
         depth_error = (depth_pred - depth_gt) * valid_depth_region * mask_gt
@@ -669,9 +672,7 @@ class ReferenceLoop:
         surf_neig_loss = r.surface_neighbour_error(rays=rays, mask=mask_gt, iter_step=global_step, neighbour_rad=0.1)
         loss = (color_loss * w["color"] + depth_loss * w["depth"] + sdf_loss * w["sdf"] + angle_loss * w["angle"]
                 + eikonal_loss * w["eikonal"] + w["surf_neig"] * surf_neig_loss)
-        if self.logging:          # (these host reads sit BEFORE the backward, as in the reference: the host waits for the forward here)
-            a, b, m = (t.detach().cpu().numpy() for t in (color_pred, color_gt, color_mask_gt))          # cal_psnr -> tensor2array
-            _psnr = 20.0 * np.log10(1.0 / (((a - b) ** 2 * m).sum() / ((np.sum(m) + 1e-10) * 3.0)) ** 0.5)
+        if self.logging:          # (the add_scalar reads sit BEFORE the backward, as in the reference: the host waits for the forward here)
             for t in (color_loss, sdf_loss, angle_loss, depth_loss, eikonal_loss, surf_neig_loss, loss, ret["s_val"].mean(),
                       (ret["cdf"][:, :1] * mask_gt).sum() / (mask_gt.sum() + 1e-10), (ret["weight_max"] * mask_gt).sum() / (mask_gt.sum() + 1e-10)):
                 self._log(t)
