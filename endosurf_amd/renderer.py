@@ -1286,7 +1286,7 @@ class EndoSurfRenderer(nn.Module):
             aux_t = _aux[1].detach().to(torch.float32).reshape(-1).contiguous()
         flags = self._flags(weff)
         chunk = self._chunk_rays(z.shape[0], z.shape[1], flags)
-        tail = self._new_tail(z.numel(), flags, chunk) if _aux is None else None
+        tail = self._new_tail(z.numel(), flags, chunk, z.shape[0]) if _aux is None else None
         color, depth, g_o, eik, weights, wmax, cdf, _, aux_sdf, aux_go, eik_den, token = _RenderFn.apply(
             weff, packed, var, self.engine, _rays, z, float(sample_dist), cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio), flags, aux_x, aux_t,
             chunk, tail)
@@ -1327,14 +1327,17 @@ class EndoSurfRenderer(nn.Module):
         return sdf, g_o
 
     # ---- the tail of a live render (see _Tail) -------------------------------------------------------------------------------------------
-    def _new_tail(self, P_: int, flags: int, chunk: int):
+    def _new_tail(self, P_: int, flags: int, chunk: int, n_rays: int = 0):
         """A ``_Tail`` for the render about to run, sized by what the calls after the PREVIOUS grad-enabled render asked for (the reference
-        trainer's step repeats the same three calls); None when nothing was asked for or the render cannot host one."""
+        trainer's step repeats the same three calls); None when nothing was asked for or the render cannot host one.  The very first
+        grad-enabled render of a renderer has no history: it assumes the reference trainer's pattern (errorondepth: one point per ray,
+        surface_neighbour_error: two) -- if nobody comes, the unclaimed rows cost one small evaluation, once."""
         if not (flags & _lib.PF_SAVE):
             return None
         if self.__dict__.get("_fwd_graphs"):
             self.release_forward_graphs()
-        demand, self._aux_demand = getattr(self, "_aux_demand", 0), 0
+        first_guess = (n_rays + 63) // 64 * 64 + (2 * n_rays + 63) // 64 * 64
+        demand, self._aux_demand = self.__dict__.get("_aux_demand", first_guess), 0
         eng = self.engine
         if demand <= 0 or chunk or P_ <= 0 or P_ % 64 or eng.split_precision or torch.cuda.is_current_stream_capturing():
             return None
